@@ -1,0 +1,410 @@
+/*
+ * t1d_oracle.c -- CPU restatement of the simglucose hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product path (simglucose_amd/) never does.  Plain C, fp64 throughout,
+ * one function per reference function, each citing the reference file:line it follows
+ * (paths relative to /root/reference).  Nothing here is copied from the reference: the
+ * reference is Python/NumPy/SciPy, this is a from-scratch C statement of the same
+ * arithmetic, pinned against golden vectors produced by running the reference itself
+ * (oracle/gen_golden.py -> tests/golden/, checked by tests/test_oracle_golden.py).
+ *
+ * Third-party algorithm restated here: scipy.integrate.ode('dopri5') = Hairer & Wanner's
+ * DOPRI5 (Dormand-Prince 5(4), scipy pins ==1.6.3 in the reference's Pipfile.lock; the
+ * installed 1.15.3 wraps the same Fortran driver).  Call sites: patient/t1dpatient.py:276-277
+ * (construction, default tolerances rtol 1e-6 / atol 1e-12) and :110-113 (one integrate()
+ * per simulated minute).  The step-size controller, the initial-step probe and the
+ * carry-over of the predicted step between calls are restated in o_dopri5_minute().
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <float.h>
+
+#include "t1d_oracle.h"
+
+/* ------------------------------------------------------------------------------------------
+ * P1: T1DPatient.model  (patient/t1dpatient.py:119-208)
+ * x[13] state, cho = grams eaten this minute (g/min), ins = U/min, lq = last_Qsto (mg),
+ * lf = last_foodtaken (g).  p points at one row of the patient table (T1D_O_* columns).
+ * ---------------------------------------------------------------------------------------- */
+void t1d_o_rhs(const double* p, const double* x, double cho, double ins, double lq, double lf,
+               double* dx)
+{
+    const double d = cho * 1000.0;                       /* :121  g -> mg               */
+    const double insulin = ins * 6000.0 / p[T1D_O_BW];   /* :122  U/min -> pmol/kg/min  */
+    const double qsto = x[0] + x[1];                     /* :126 */
+    const double Dbar = lq + lf * 1000.0;                /* :130 */
+    double kgut;
+
+    dx[0] = -p[T1D_O_KMAX] * x[0] + d;                   /* :133 */
+    if (Dbar > 0.0) {                                    /* :135-140 */
+        const double aa = 5.0 / 2.0 / (1.0 - p[T1D_O_B]) / Dbar;
+        const double cc = 5.0 / 2.0 / p[T1D_O_D] / Dbar;
+        kgut = p[T1D_O_KMIN] + (p[T1D_O_KMAX] - p[T1D_O_KMIN]) / 2.0 *
+               (tanh(aa * (qsto - p[T1D_O_B] * Dbar)) - tanh(cc * (qsto - p[T1D_O_D] * Dbar)) + 2.0);
+    } else {
+        kgut = p[T1D_O_KMAX];                            /* :142 */
+    }
+    dx[1] = p[T1D_O_KMAX] * x[0] - x[1] * kgut;          /* :145 */
+    dx[2] = kgut * x[1] - p[T1D_O_KABS] * x[2];          /* :148 */
+
+    const double Rat = p[T1D_O_F] * p[T1D_O_KABS] * x[2] / p[T1D_O_BW];          /* :151 */
+    const double EGPt = p[T1D_O_KP1] - p[T1D_O_KP2] * x[3] - p[T1D_O_KP3] * x[8];/* :153 */
+    const double Uiit = p[T1D_O_FSNC];                                           /* :155 */
+    const double Et = (x[3] > p[T1D_O_KE2]) ? p[T1D_O_KE1] * (x[3] - p[T1D_O_KE2]) : 0.0; /* :158-161 */
+
+    dx[3] = (EGPt > 0.0 ? EGPt : 0.0) + Rat - Uiit - Et - p[T1D_O_K1] * x[3] + p[T1D_O_K2] * x[4]; /* :165 */
+    dx[3] = (x[3] >= 0.0) ? dx[3] : 0.0 * dx[3];         /* :167  (bool * value)         */
+
+    const double Vmt = p[T1D_O_VM0] + p[T1D_O_VMX] * x[6];                       /* :169 */
+    const double Uidt = Vmt * x[4] / (p[T1D_O_KM0] + x[4]);                      /* :171 */
+    dx[4] = -Uidt + p[T1D_O_K1] * x[3] - p[T1D_O_K2] * x[4];                     /* :172 */
+    dx[4] = (x[4] >= 0.0) ? dx[4] : 0.0 * dx[4];                                 /* :173 */
+
+    dx[5] = -(p[T1D_O_M2] + p[T1D_O_M4]) * x[5] + p[T1D_O_M1] * x[9] + p[T1D_O_KA1] * x[10] +
+            p[T1D_O_KA2] * x[11];                                                /* :176 */
+    const double It = x[5] / p[T1D_O_VI];                                        /* :178 */
+    dx[5] = (x[5] >= 0.0) ? dx[5] : 0.0 * dx[5];                                 /* :179 */
+
+    dx[6] = -p[T1D_O_P2U] * x[6] + p[T1D_O_P2U] * (It - p[T1D_O_IB]);            /* :182 */
+    dx[7] = -p[T1D_O_KI] * (x[7] - It);                                          /* :185 */
+    dx[8] = -p[T1D_O_KI] * (x[8] - x[7]);                                        /* :187 */
+
+    dx[9] = -(p[T1D_O_M1] + p[T1D_O_M30]) * x[9] + p[T1D_O_M2] * x[5];           /* :190 */
+    dx[9] = (x[9] >= 0.0) ? dx[9] : 0.0 * dx[9];                                 /* :191 */
+
+    dx[10] = insulin - (p[T1D_O_KA1] + p[T1D_O_KD]) * x[10];                     /* :194 */
+    dx[10] = (x[10] >= 0.0) ? dx[10] : 0.0 * dx[10];                             /* :195 */
+    dx[11] = p[T1D_O_KD] * x[10] - p[T1D_O_KA2] * x[11];                         /* :197 */
+    dx[11] = (x[11] >= 0.0) ? dx[11] : 0.0 * dx[11];                             /* :198 */
+    dx[12] = (-p[T1D_O_KSC] * x[12] + p[T1D_O_KSC] * x[3]);                      /* :201 */
+    dx[12] = (x[12] >= 0.0) ? dx[12] : 0.0 * dx[12];                             /* :202 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Fixed-step classical RK4 over one minute in n_sub sub-steps: the integrator the HIP kernel
+ * uses in place of P2 (BASELINE.json north_star).  Inputs are constant over the minute, as
+ * they are in patient/t1dpatient.py:110-113 (set_f_params once per integrate()).
+ * ---------------------------------------------------------------------------------------- */
+void t1d_o_rk4_minute(const double* p, double* x, double cho, double ins, double lq, double lf,
+                      int n_sub)
+{
+    const double h = 1.0 / (double)n_sub;
+    double k1[13], k2[13], k3[13], k4[13], y[13];
+    for (int s = 0; s < n_sub; ++s) {
+        t1d_o_rhs(p, x, cho, ins, lq, lf, k1);
+        for (int i = 0; i < 13; ++i) y[i] = x[i] + 0.5 * h * k1[i];
+        t1d_o_rhs(p, y, cho, ins, lq, lf, k2);
+        for (int i = 0; i < 13; ++i) y[i] = x[i] + 0.5 * h * k2[i];
+        t1d_o_rhs(p, y, cho, ins, lq, lf, k3);
+        for (int i = 0; i < 13; ++i) y[i] = x[i] + h * k3[i];
+        t1d_o_rhs(p, y, cho, ins, lq, lf, k4);
+        for (int i = 0; i < 13; ++i) x[i] = x[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * P2: scipy.integrate.ode(...).set_integrator('dopri5').integrate(t+1)
+ *     (patient/t1dpatient.py:276-277 construction, :110-113 one call per minute).
+ * Hairer's DOPRI5 driver is re-entered for every minute on [t, t+1]; scipy passes the same
+ * work array each time, so only the predicted step size `*h_carry` survives between calls
+ * (0 on the first call after reset -> automatic initial-step probe).  Settings as scipy's
+ * wrapper passes them: rtol 1e-6, atol 1e-12, nmax 500, safety 0.9, fac1 0.2, fac2 10,
+ * beta: the wrapper writes 0.0 into work(5), which the driver reads as "use the default 0.04".
+ * hmax = the interval length.  Returns the number of RHS evaluations, or -1 on failure.
+ * ---------------------------------------------------------------------------------------- */
+static double o_hinit(const double* p, const double* y, const double* f0, double cho, double ins,
+                      double lq, double lf, double hmax, double atol, double rtol)
+{
+    double dnf = 0.0, dny = 0.0, y1[13], f1[13];
+    for (int i = 0; i < 13; ++i) {
+        const double sk = atol + rtol * fabs(y[i]);
+        dnf += (f0[i] / sk) * (f0[i] / sk);
+        dny += (y[i] / sk) * (y[i] / sk);
+    }
+    double h = (dnf <= 1e-10 || dny <= 1e-10) ? 1e-6 : sqrt(dny / dnf) * 0.01;
+    if (h > hmax) h = hmax;
+    for (int i = 0; i < 13; ++i) y1[i] = y[i] + h * f0[i];
+    t1d_o_rhs(p, y1, cho, ins, lq, lf, f1);
+    double der2 = 0.0;
+    for (int i = 0; i < 13; ++i) {
+        const double sk = atol + rtol * fabs(y[i]);
+        der2 += ((f1[i] - f0[i]) / sk) * ((f1[i] - f0[i]) / sk);
+    }
+    der2 = sqrt(der2) / h;
+    const double der12 = fmax(fabs(der2), sqrt(dnf));
+    double h1 = (der12 <= 1e-15) ? fmax(1e-6, fabs(h) * 1e-3) : pow(0.01 / der12, 1.0 / 5.0);
+    h = fmin(fmin(100.0 * fabs(h), h1), hmax);
+    return h;
+}
+
+int t1d_o_dopri5_minute(const double* p, double* y, double cho, double ins, double lq, double lf,
+                        double* h_carry, double beta, double t_start)
+{
+    static const double a21 = 0.2, a31 = 3.0 / 40.0, a32 = 9.0 / 40.0, a41 = 44.0 / 45.0,
+        a42 = -56.0 / 15.0, a43 = 32.0 / 9.0, a51 = 19372.0 / 6561.0, a52 = -25360.0 / 2187.0,
+        a53 = 64448.0 / 6561.0, a54 = -212.0 / 729.0, a61 = 9017.0 / 3168.0, a62 = -355.0 / 33.0,
+        a63 = 46732.0 / 5247.0, a64 = 49.0 / 176.0, a65 = -5103.0 / 18656.0, a71 = 35.0 / 384.0,
+        a73 = 500.0 / 1113.0, a74 = 125.0 / 192.0, a75 = -2187.0 / 6784.0, a76 = 11.0 / 84.0,
+        e1 = 71.0 / 57600.0, e3 = -71.0 / 16695.0, e4 = 71.0 / 1920.0, e5 = -17253.0 / 339200.0,
+        e6 = 22.0 / 525.0, e7 = -1.0 / 40.0;
+    const double rtol = 1e-6, atol = 1e-12, safe = 0.9, fac1 = 0.2, fac2 = 10.0, uround = 2.3e-16;
+    const int nmax = 500;
+    const double expo1 = 0.2 - beta * 0.75, facc1 = 1.0 / fac1, facc2 = 1.0 / fac2;
+    const double xend = t_start + 1.0, hmax = 1.0;
+    double x = t_start, h = *h_carry, facold = 1e-4;
+    double k1[13], k2[13], k3[13], k4[13], k5[13], k6[13], y1[13], ysti[13];
+    int nfcn = 0, nstep = 0, last = 0, reject = 0;
+
+    t1d_o_rhs(p, y, cho, ins, lq, lf, k1); nfcn++;
+    if (h == 0.0) { h = o_hinit(p, y, k1, cho, ins, lq, lf, hmax, atol, rtol); nfcn++; }
+    for (;;) {
+        if (nstep > nmax) return -1;
+        if (0.1 * fabs(h) <= fabs(x) * uround) return -1;
+        if ((x + 1.01 * h - xend) > 0.0) { h = xend - x; last = 1; }
+        nstep++;
+        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h * a21 * k1[i];
+        t1d_o_rhs(p, y1, cho, ins, lq, lf, k2);
+        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h * (a31 * k1[i] + a32 * k2[i]);
+        t1d_o_rhs(p, y1, cho, ins, lq, lf, k3);
+        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+        t1d_o_rhs(p, y1, cho, ins, lq, lf, k4);
+        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+        t1d_o_rhs(p, y1, cho, ins, lq, lf, k5);
+        for (int i = 0; i < 13; ++i) ysti[i] = y[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+        t1d_o_rhs(p, ysti, cho, ins, lq, lf, k6);
+        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h * (a71 * k1[i] + a73 * k3[i] + a74 * k4[i] + a75 * k5[i] + a76 * k6[i]);
+        t1d_o_rhs(p, y1, cho, ins, lq, lf, k2);
+        nfcn += 6;
+        double err = 0.0;
+        for (int i = 0; i < 13; ++i) {
+            const double ke = (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k2[i]) * h;
+            const double sk = atol + rtol * fmax(fabs(y[i]), fabs(y1[i]));
+            err += (ke / sk) * (ke / sk);
+        }
+        err = sqrt(err / 13.0);
+        const double fac11 = pow(err, expo1);
+        double fac = fac11 / pow(facold, beta);
+        fac = fmax(facc2, fmin(facc1, fac / safe));
+        double hnew = h / fac;
+        if (err <= 1.0) {
+            facold = fmax(err, 1e-4);
+            for (int i = 0; i < 13; ++i) { k1[i] = k2[i]; y[i] = y1[i]; }
+            x += h;
+            if (last) { *h_carry = hnew; return nfcn; }
+            if (fabs(hnew) > hmax) hnew = hmax;
+            if (reject) hnew = fmin(fabs(hnew), fabs(h));
+            reject = 0;
+        } else {
+            hnew = h / fmin(facc1, fac11 / safe);
+            reject = 1;
+            last = 0;
+        }
+        h = hnew;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A1: InsulinPump.basal / .bolus (actuator/pump.py:23-39).  np.round = round-half-to-even,
+ * which is rint() under the default rounding mode.  Both use the same arithmetic with their
+ * own (inc, min, max).
+ * ---------------------------------------------------------------------------------------- */
+double t1d_o_pump(double amount, double inc, double lo, double hi)
+{
+    double v = amount * 6000.0;          /* :24 / :33 */
+    v = rint(v / inc) * inc;             /* :25-26 / :34-35 */
+    v = v / 6000.0;                      /* :27 / :36 */
+    v = (v < hi) ? v : hi;               /* min(v, max)  :28 / :37 */
+    v = (v > lo) ? v : lo;               /* max(v, min)  :29 / :38 */
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R1: risk_index([BG], 1) (analysis/risk.py:5-17) for a single value.  Empty-slice means turn
+ * into NaN -> nan_to_num -> 0; an infinite value -> DBL_MAX the same way.
+ * ---------------------------------------------------------------------------------------- */
+void t1d_o_risk(double bg, double* lbgi, double* hbgi, double* ri)
+{
+    const double f = 1.509 * (pow(log(bg), 1.084) - 5.381);   /* :11 */
+    double l = 0.0, hh = 0.0;
+    if (f < 0.0) l = 10.0 * f * f;                            /* :12,14 */
+    if (f > 0.0) hh = 10.0 * f * f;                           /* :13,15 */
+    if (isinf(l)) l = DBL_MAX;
+    if (isinf(hh)) hh = DBL_MAX;
+    *lbgi = l; *hbgi = hh; *ri = l + hh;                      /* :16 */
+}
+
+/* S2: johnson_transform_SU (sensor/noise_gen.py:11-12) */
+static double o_johnson(const double* s, double e)
+{
+    return s[T1D_O_S_XI] + s[T1D_O_S_LAMBDA] * sinh((e - s[T1D_O_S_GAMMA]) / s[T1D_O_S_DELTA]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * S2: next(CGMNoise) (sensor/noise_gen.py:61-69 with the refill :30-56 and the AR(1) source
+ * :84-97).  State per env: AR value e, the 11 fifteen-minute points of the current block,
+ * the count of samples handed out and of normals consumed.  The cubic-spline block is the
+ * fixed linear operator W [w_rows x 11] (rows sum to 1; verified against the reference in
+ * tests/golden/g4_sensor.npz).  `z` = this env's standard normals, indexed by draw count.
+ * ---------------------------------------------------------------------------------------- */
+static double o_noise_next(t1d_o_batch* b, int i)
+{
+    const int n = b->n, S = b->w_rows;
+    const int j = b->n_samples[i] % S;
+    if (j == 0) {                                   /* deque empty -> _get_noise_seq */
+        /* first point = carried-over last point (noise_gen.py:33-36) */
+        if (b->n_samples[i] > 0) b->pts[0 * n + i] = b->pts[10 * n + i];
+        for (int k = 1; k <= 10; ++k) {             /* :34  ten new 15-min points */
+            const double z = b->normals[(size_t)b->n_draws[i] * n + i];
+            b->n_draws[i]++;
+            b->ar_e[i] = b->sensor[T1D_O_S_PACF] * (b->ar_e[i] + z);   /* :88 */
+            b->pts[k * n + i] = o_johnson(b->sensor, b->ar_e[i]);
+        }
+    }
+    double acc = 0.0;
+    for (int k = 0; k < 11; ++k) acc += b->W[j * 11 + k] * b->pts[k * n + i];
+    b->n_samples[i]++;
+    return acc;
+}
+
+/* S1: CGMSensor.measure (sensor/cgm.py:26-36) at patient time t (minutes, after the step) */
+static double o_measure(t1d_o_batch* b, int i, double gsub)
+{
+    const double st = b->sensor[T1D_O_S_SAMPLE_TIME];
+    if (fmod((double)b->t[i], st) == 0.0) {
+        double cgm = gsub + o_noise_next(b, i);
+        cgm = fmax(cgm, b->sensor[T1D_O_S_MIN]);
+        cgm = fmin(cgm, b->sensor[T1D_O_S_MAX]);
+        b->last_cgm[i] = cgm;
+        return cgm;
+    }
+    return b->last_cgm[i];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E3/P4/S1: T1DSimEnv.reset() (simulation/env.py:119-155) on every env of the batch:
+ * patient.reset (patient/t1dpatient.py:247-281, x0 = columns x0_1..x0_13, or the caller's
+ * init_state when x0_override != NULL -- how random_init_bg draws made on the host enter),
+ * sensor.reset (sensor/cgm.py:47-50: new noise generator => consumes normal #0),
+ * _reset (env.py:119-134: BG0, risk, CGM sample #0 -> history[0]) and the returned
+ * observation = CGM sample #1 (env.py:142).
+ * ---------------------------------------------------------------------------------------- */
+void t1d_o_reset(t1d_o_batch* b, const double* x0_override, t1d_o_out* o)
+{
+    const int n = b->n;
+    for (int i = 0; i < n; ++i) {
+        const double* p = b->ptab + (size_t)b->pid[i] * T1D_O_NPAR;
+        for (int k = 0; k < 13; ++k)
+            b->x[k * n + i] = x0_override ? x0_override[k * n + i] : p[T1D_O_X0 + k];
+        b->planned[i] = 0.0;
+        b->last_qsto[i] = b->x[0 * n + i] + b->x[1 * n + i];    /* t1dpatient.py:272 */
+        b->last_food[i] = 0.0;
+        b->was_eating[i] = 0;
+        b->t[i] = 0;
+        b->h_carry[i] = 0.0;
+        /* sensor */
+        b->last_cgm[i] = 0.0; b->n_samples[i] = 0; b->n_draws[i] = 0;
+        b->ar_e[i] = b->normals[(size_t)0 * n + i]; b->n_draws[i] = 1;          /* noise_gen.py:86 */
+        for (int k = 0; k < 11; ++k) b->pts[k * n + i] = 0.0;
+        b->pts[0 * n + i] = o_johnson(b->sensor, b->ar_e[i]);                  /* noise_gen.py:24 */
+        const double bg0 = b->x[12 * n + i] / p[T1D_O_VG];
+        const double cgm0 = o_measure(b, i, bg0);        /* env.py:126 */
+        const double cgm1 = o_measure(b, i, bg0);        /* env.py:142 */
+        b->prev_cgm[i] = cgm0;                           /* CGM_hist[0] */
+        if (o) {
+            o->cgm[i] = cgm1; o->bg[i] = bg0; o->reward[i] = 0.0; o->done[i] = 0; o->meal[i] = 0.0;
+            o->insulin[i] = 0.0; o->cgm_hist0[i] = cgm0;
+            t1d_o_risk(bg0, &o->lbgi[i], &o->hbgi[i], &o->risk[i]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E2: T1DSimEnv.step (simulation/env.py:66-117) = int(sample_time) x E1 mini_step
+ * (env.py:48-64), with P3 T1DPatient.step bookkeeping (patient/t1dpatient.py:82-107,222-236),
+ * the default reward risk_diff (env.py:27-33) on the CGM history, and done (env.py:103).
+ * cho[m*n+i] = grams the scenario announces to env i in minute m of this step.
+ * integrator: 0 = RK4(n_sub), 1 = DOPRI5 as SciPy runs it (beta in `dopri_beta`).
+ * Returns 0, or -1 if the adaptive solver failed for some env.
+ * ---------------------------------------------------------------------------------------- */
+int t1d_o_step(t1d_o_batch* b, const double* basal, const double* bolus, const double* cho,
+               int integrator, int n_sub, double dopri_beta, t1d_o_out* o)
+{
+    const int n = b->n;
+    const double st = b->sensor[T1D_O_S_SAMPLE_TIME];
+    const int nmin = (int)st;
+    int rc = 0;
+    for (int i = 0; i < n; ++i) {
+        const double* p = b->ptab + (size_t)b->pid[i] * T1D_O_NPAR;
+        double x[13];
+        for (int k = 0; k < 13; ++k) x[k] = b->x[k * n + i];
+        double a_cho = 0.0, a_ins = 0.0, a_bg = 0.0, a_cgm = 0.0;
+        const double q_basal = t1d_o_pump(basal[i], b->pump[T1D_O_PU_INC_BASAL], b->pump[T1D_O_PU_MIN_BASAL], b->pump[T1D_O_PU_MAX_BASAL]);
+        const double q_bolus = t1d_o_pump(bolus ? bolus[i] : 0.0, b->pump[T1D_O_PU_INC_BOLUS], b->pump[T1D_O_PU_MIN_BOLUS], b->pump[T1D_O_PU_MAX_BOLUS]);
+        const double insulin = q_basal + q_bolus;                       /* env.py:51-53 */
+        for (int m = 0; m < nmin; ++m) {
+            const double meal = cho ? cho[(size_t)m * n + i] : 0.0;     /* env.py:50,54 */
+            /* _announce_meal (t1dpatient.py:222-236) */
+            double to_eat = 0.0;
+            b->planned[i] += meal;
+            if (b->planned[i] > 0.0) {
+                to_eat = fmin(5.0, b->planned[i]);
+                b->planned[i] -= to_eat;
+                b->planned[i] = fmax(0.0, b->planned[i]);
+            }
+            /* eating edges (t1dpatient.py:88-107) */
+            if (to_eat > 0.0 && !b->was_eating[i]) { b->last_qsto[i] = x[0] + x[1]; b->last_food[i] = 0.0; }
+            b->last_food[i] += to_eat;          /* is_eating <=> to_eat > 0 after the edge test */
+            b->was_eating[i] = (to_eat > 0.0);
+            if (integrator == 0) {
+                t1d_o_rk4_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub);
+            } else {
+                if (t1d_o_dopri5_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i],
+                                        &b->h_carry[i], dopri_beta, (double)b->t[i]) < 0) rc = -1;
+            }
+            b->t[i] += 1;
+            const double bg = x[12] / p[T1D_O_VG];                      /* env.py:61 */
+            const double cgm = o_measure(b, i, bg);                     /* env.py:62 */
+            a_cho += meal / st; a_ins += insulin / st; a_bg += bg / st; a_cgm += cgm / st;  /* env.py:78-81 */
+        }
+        for (int k = 0; k < 13; ++k) b->x[k * n + i] = x[k];
+        double rp, rcur, l, hh;
+        t1d_o_risk(b->prev_cgm[i], &l, &hh, &rp);                       /* env.py:27-33 */
+        t1d_o_risk(a_cgm, &l, &hh, &rcur);
+        if (o) {
+            o->cgm[i] = a_cgm; o->bg[i] = a_bg; o->meal[i] = a_cho; o->insulin[i] = a_ins;
+            o->reward[i] = rp - rcur;
+            o->done[i] = (a_bg < 70.0 || a_bg > 350.0);                 /* env.py:103 */
+            t1d_o_risk(a_bg, &o->lbgi[i], &o->hbgi[i], &o->risk[i]);    /* env.py:85 */
+        }
+        b->prev_cgm[i] = a_cgm;
+    }
+    return rc;
+}
+
+/* C1: PIDController.policy (controller/pid_ctrller.py:17-36) -> basal U/min */
+double t1d_o_pid(double* integ, double* prev, double cgm, double P, double I, double D, double target,
+                 double sample_time)
+{
+    const double u = P * (cgm - target) + I * (*integ) + D * (cgm - *prev) / sample_time;  /* :22-24 */
+    *prev = cgm;                                    /* :29 */
+    *integ += (cgm - target) * sample_time;          /* :30 */
+    return u;
+}
+
+/* Patient-only minute: T1DPatient.step(Action(CHO, insulin)) without env/sensor/pump, used by
+ * the G2 open-loop pins (patient/t1dpatient.py:82-116). */
+int t1d_o_patient_minute(const double* p, double* x, double* planned, double* last_qsto, double* last_food,
+                         uint8_t* was_eating, double* h_carry, int t, double meal, double insulin,
+                         int integrator, int n_sub, double dopri_beta)
+{
+    double to_eat = 0.0;
+    *planned += meal;
+    if (*planned > 0.0) { to_eat = fmin(5.0, *planned); *planned -= to_eat; *planned = fmax(0.0, *planned); }
+    if (to_eat > 0.0 && !*was_eating) { *last_qsto = x[0] + x[1]; *last_food = 0.0; }
+    *last_food += to_eat;
+    *was_eating = (to_eat > 0.0);
+    if (integrator == 0) { t1d_o_rk4_minute(p, x, to_eat, insulin, *last_qsto, *last_food, n_sub); return 4 * n_sub; }
+    return t1d_o_dopri5_minute(p, x, to_eat, insulin, *last_qsto, *last_food, h_carry, dopri_beta, (double)t);
+}

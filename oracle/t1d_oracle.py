@@ -1,0 +1,298 @@
+"""ctypes/numpy front-end of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; nothing under ``simglucose_amd/`` does.  The numerics live in ``t1d_oracle.c``
+(each function cites the reference file:line it restates); this file only marshals numpy
+arrays, builds the parameter rows from the shipped CSV data tables and restates the two small
+host-side pieces of the path that are easier to state in numpy:
+
+* the not-a-knot cubic-spline block operator ``W`` behind ``scipy.interpolate.interp1d(kind=
+  'cubic')`` in ``sensor/noise_gen.py:45-47`` (pinned by ``tests/golden/g4_sensor.npz``);
+* ``RandomScenario.create_scenario`` / ``get_action`` (``simulation/scenario_gen.py:15-60``) and
+  ``CustomScenario.get_action`` (``simulation/scenario.py:33-59``) as per-minute CHO arrays
+  (pinned by ``tests/golden/g9_seeding.npz``).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PARAMS = os.path.join(os.path.dirname(_HERE), "simglucose_amd", "params")
+
+PAR_COLS = ["BW", "kabs", "kmax", "kmin", "b", "d", "Vg", "Vi", "Vmx", "Km0", "k2", "k1", "p2u",
+            "m1", "m2", "m4", "m30", "Ib", "ki", "kp2", "kp3", "f", "ke1", "ke2", "Fsnc", "Vm0",
+            "kd", "ksc", "ka1", "ka2", "kp1", "u2ss"]
+NPAR = 13 + len(PAR_COLS)
+IDX = {name: 13 + i for i, name in enumerate(PAR_COLS)}
+SENSOR_COLS = ["PACF", "gamma", "lambda", "delta", "xi", "sample_time", "min", "max"]
+PUMP_COLS = ["min_bolus", "max_bolus", "inc_bolus", "min_basal", "max_basal", "inc_basal"]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libt1d_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("t1d_oracle.c", "t1d_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libt1d_oracle.so"])
+    return so
+
+
+def _read_csv(path):
+    import csv
+    with open(path, newline="") as f:
+        rows = list(csv.reader(f))
+    return rows[0], rows[1:]
+
+
+def patient_table():
+    """-> (names, table[30, NPAR]) in the column order of t1d_oracle.h."""
+    hdr, rows = _read_csv(os.path.join(_PARAMS, "vpatient_params.csv"))
+    col = {h: i for i, h in enumerate(hdr)}
+    names = [r[col["Name"]] for r in rows]
+    tab = np.empty((len(rows), NPAR))
+    for i, r in enumerate(rows):
+        tab[i, :13] = [float(v) for v in r[2:15]]
+        tab[i, 13:] = [float(r[col[c]]) for c in PAR_COLS]
+    return names, tab
+
+
+def sensor_row(name):
+    hdr, rows = _read_csv(os.path.join(_PARAMS, "sensor_params.csv"))
+    r = next(r for r in rows if r[0] == name)
+    return np.array([float(r[hdr.index(c)]) for c in SENSOR_COLS])
+
+
+def pump_row(name):
+    hdr, rows = _read_csv(os.path.join(_PARAMS, "pump_params.csv"))
+    r = next(r for r in rows if r[0] == name)
+    return np.array([float(r[hdr.index(c)]) for c in PUMP_COLS])
+
+
+def spline_block_operator(sample_time):
+    """W[(floor(150/st)) x 11]: noise block samples = W @ (11 points at 15-min spacing).
+
+    Not-a-knot cubic spline through 11 equally spaced knots (what interp1d(kind='cubic')
+    builds), evaluated at t = st, 2 st, ... (first sample dropped, noise_gen.py:47).
+    """
+    h, K = 15.0, 11
+    A = np.zeros((K, K)); B = np.zeros((K, K))
+    for k in range(1, K - 1):
+        A[k, k - 1:k + 2] = (1.0, 4.0, 1.0)
+        B[k, k - 1:k + 2] = np.array([1.0, -2.0, 1.0]) * 6.0 / h ** 2
+    A[0, 0:3] = (1.0, -2.0, 1.0)
+    A[K - 1, K - 3:K] = (1.0, -2.0, 1.0)
+    M = np.linalg.solve(A, B)                     # second derivatives = M @ y
+    nsample = int(np.floor(10 * 15 / sample_time)) + 1
+    t = np.arange(1, nsample) * float(sample_time)
+    W = np.zeros((len(t), K))
+    for r, tt in enumerate(t):
+        k = min(int(tt // h), K - 2)
+        a, b = (k + 1) * h - tt, tt - k * h
+        W[r] += M[k] * (a ** 3 / (6 * h) - a * h / 6) + M[k + 1] * (b ** 3 / (6 * h) - b * h / 6)
+        W[r, k] += a / h
+        W[r, k + 1] += b / h
+    return W
+
+
+# ----------------------------------------------------------------------------- ctypes structs
+_d = C.POINTER(C.c_double); _i = C.POINTER(C.c_int32); _u = C.POINTER(C.c_uint8)
+
+
+class _Batch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("w_rows", C.c_int32), ("ptab", _d), ("pid", _i), ("W", _d),
+                ("normals", _d), ("sensor", C.c_double * 8), ("pump", C.c_double * 6),
+                ("x", _d), ("planned", _d), ("last_qsto", _d), ("last_food", _d), ("was_eating", _u),
+                ("t", _i), ("h_carry", _d), ("last_cgm", _d), ("ar_e", _d), ("pts", _d),
+                ("n_samples", _i), ("n_draws", _i), ("prev_cgm", _d)]
+
+
+class _Out(C.Structure):
+    _fields_ = [(k, _d) for k in ("cgm", "bg", "reward", "lbgi", "hbgi", "risk", "meal", "insulin",
+                                  "cgm_hist0")] + [("done", _u)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.t1d_o_rhs.argtypes = [_d, _d, C.c_double, C.c_double, C.c_double, C.c_double, _d]
+        L.t1d_o_rk4_minute.argtypes = [_d, _d, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.t1d_o_dopri5_minute.argtypes = [_d, _d, C.c_double, C.c_double, C.c_double, C.c_double, _d,
+                                          C.c_double, C.c_double]
+        L.t1d_o_dopri5_minute.restype = C.c_int
+        L.t1d_o_pump.argtypes = [C.c_double] * 4; L.t1d_o_pump.restype = C.c_double
+        L.t1d_o_risk.argtypes = [C.c_double, _d, _d, _d]
+        L.t1d_o_reset.argtypes = [C.POINTER(_Batch), _d, C.POINTER(_Out)]
+        L.t1d_o_step.argtypes = [C.POINTER(_Batch), _d, _d, _d, C.c_int, C.c_int, C.c_double, C.POINTER(_Out)]
+        L.t1d_o_step.restype = C.c_int
+        L.t1d_o_pid.argtypes = [_d, _d] + [C.c_double] * 6; L.t1d_o_pid.restype = C.c_double
+        L.t1d_o_patient_minute.argtypes = [_d, _d, _d, _d, _d, _u, _d, C.c_int, C.c_double, C.c_double,
+                                           C.c_int, C.c_int, C.c_double]
+        L.t1d_o_patient_minute.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a, typ=_d):
+    return a.ctypes.data_as(typ)
+
+
+def rhs(prow, x, cho, ins, lq, lf):
+    prow = np.ascontiguousarray(prow, dtype=np.float64); x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(13)
+    lib().t1d_o_rhs(_p(prow), _p(x), cho, ins, lq, lf, _p(out))
+    return out
+
+
+def pump(amount, inc, lo, hi):
+    return lib().t1d_o_pump(float(amount), float(inc), float(lo), float(hi))
+
+
+def risk(bg):
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib().t1d_o_risk(float(bg), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+DOPRI_BETA = 0.04     # what the Fortran driver uses when scipy hands it beta = 0.0
+
+
+class PatientOracle:
+    """T1DPatient.step restated (patient only; no pump/sensor) -- pins G2."""
+
+    def __init__(self, prow, x0=None):
+        self.p = np.ascontiguousarray(prow, dtype=np.float64)
+        self.x = np.array(self.p[:13] if x0 is None else x0, dtype=np.float64)
+        self.planned = C.c_double(0.0); self.lq = C.c_double(self.x[0] + self.x[1]); self.lf = C.c_double(0.0)
+        self.eat = C.c_uint8(0); self.h = C.c_double(0.0); self.t = 0
+        self.nfcn = 0
+
+    def step(self, meal, insulin, integrator="rk4", n_sub=4, beta=DOPRI_BETA):
+        r = lib().t1d_o_patient_minute(_p(self.p), _p(self.x), C.byref(self.planned), C.byref(self.lq),
+                                       C.byref(self.lf), C.byref(self.eat), C.byref(self.h), self.t,
+                                       float(meal), float(insulin), 0 if integrator == "rk4" else 1,
+                                       int(n_sub), float(beta))
+        if r < 0:
+            raise RuntimeError("oracle DOPRI5 failed")
+        self.nfcn = r
+        self.t += 1
+        return self.x
+
+
+class OracleEnv:
+    """Batch of T1DSimEnv restated on the CPU (env index fastest, fp64)."""
+
+    OUT_KEYS = ("cgm", "bg", "reward", "lbgi", "hbgi", "risk", "meal", "insulin", "cgm_hist0")
+
+    def __init__(self, patient_idx, sensor="Dexcom", pump="Insulet", normals=None, n_draws_max=256,
+                 integrator="rk4", n_sub=4, beta=DOPRI_BETA, sensor_row_override=None):
+        self.names, self.ptab = patient_table()
+        self.pid = np.ascontiguousarray(patient_idx, dtype=np.int32)
+        n = self.n = len(self.pid)
+        self.sensor = np.array(sensor_row_override if sensor_row_override is not None else sensor_row(sensor))
+        self.pump = pump_row(pump)
+        self.W = np.ascontiguousarray(spline_block_operator(self.sensor[5]))
+        self.normals = np.ascontiguousarray(
+            normals if normals is not None else np.zeros((n_draws_max, n)), dtype=np.float64)
+        assert self.normals.shape[1] == n
+        self.integrator, self.n_sub, self.beta = integrator, n_sub, beta
+        z = lambda *s: np.zeros(s)
+        self.x = z(13, n); self.planned = z(n); self.last_qsto = z(n); self.last_food = z(n)
+        self.was_eating = np.zeros(n, np.uint8); self.t = np.zeros(n, np.int32); self.h_carry = z(n)
+        self.last_cgm = z(n); self.ar_e = z(n); self.pts = z(11, n)
+        self.n_samples = np.zeros(n, np.int32); self.n_draws = np.zeros(n, np.int32); self.prev_cgm = z(n)
+        self.out = {k: z(n) for k in self.OUT_KEYS}; self.out["done"] = np.zeros(n, np.uint8)
+        b = self._b = _Batch()
+        b.n, b.w_rows = n, self.W.shape[0]
+        b.ptab, b.pid, b.W, b.normals = _p(self.ptab), _p(self.pid, _i), _p(self.W), _p(self.normals)
+        for k in range(8): b.sensor[k] = self.sensor[k]
+        for k in range(6): b.pump[k] = self.pump[k]
+        for k in ("x", "planned", "last_qsto", "last_food", "h_carry", "last_cgm", "ar_e", "pts", "prev_cgm"):
+            setattr(b, k, _p(getattr(self, k)))
+        b.was_eating = _p(self.was_eating, _u); b.t = _p(self.t, _i)
+        b.n_samples = _p(self.n_samples, _i); b.n_draws = _p(self.n_draws, _i)
+        o = self._o = _Out()
+        for k in self.OUT_KEYS: setattr(o, k, _p(self.out[k]))
+        o.done = _p(self.out["done"], _u)
+
+    @property
+    def sample_time(self):
+        return self.sensor[5]
+
+    def reset(self, x0=None):
+        x0p = None
+        if x0 is not None:
+            self._x0 = np.ascontiguousarray(x0, dtype=np.float64); assert self._x0.shape == (13, self.n)
+            x0p = _p(self._x0)
+        lib().t1d_o_reset(C.byref(self._b), x0p, C.byref(self._o))
+        return {k: v.copy() for k, v in self.out.items()}
+
+    def step(self, basal, bolus=None, cho=None):
+        n = self.n
+        basal = np.ascontiguousarray(np.broadcast_to(np.asarray(basal, dtype=np.float64), (n,)))
+        bp = None
+        if bolus is not None:
+            bolus = np.ascontiguousarray(np.broadcast_to(np.asarray(bolus, dtype=np.float64), (n,))); bp = _p(bolus)
+        cp = None
+        if cho is not None:
+            cho = np.ascontiguousarray(cho, dtype=np.float64); assert cho.shape == (int(self.sample_time), n)
+            cp = _p(cho)
+        rc = lib().t1d_o_step(C.byref(self._b), _p(basal), bp, cp, 0 if self.integrator == "rk4" else 1,
+                              int(self.n_sub), float(self.beta), C.byref(self._o))
+        if rc != 0:
+            raise RuntimeError("oracle DOPRI5 failed")
+        return {k: v.copy() for k, v in self.out.items()}
+
+
+# ----------------------------------------------------------------------------- scenarios (M1)
+def custom_scenario_cho(hours, grams, n_minutes):
+    """CustomScenario with numeric times = hours after start (scenario.py:33-59): CHO per minute.
+    First match wins when two entries round to the same minute (list.index, scenario.py:40)."""
+    cho = np.zeros(n_minutes)
+    seen = set()
+    for h, g in zip(hours, grams):
+        m = int(round(h * 60.0))
+        if m in seen:
+            continue
+        seen.add(m)
+        if 0 <= m < n_minutes:
+            cho[m] = g
+    return cho
+
+
+def random_scenario_draw(rs):
+    """One RandomScenario.create_scenario() draw from a numpy RandomState (scenario_gen.py:33-60).
+    scipy.stats.truncnorm.rvs draws one uniform from the same RandomState and maps it through
+    the truncated-normal inverse CDF."""
+    from scipy.stats import truncnorm
+    prob = [0.95, 0.3, 0.95, 0.3, 0.95, 0.3]
+    lb = np.array([5, 9, 10, 14, 16, 20]) * 60; ub = np.array([9, 10, 14, 16, 20, 23]) * 60
+    mu = np.array([7, 9.5, 12, 15, 18, 21.5]) * 60; sd = np.array([60, 30, 60, 30, 60, 30])
+    amu = [45, 10, 70, 10, 80, 10]; asd = [10, 5, 10, 5, 10, 5]
+    times, amounts = [], []
+    for k in range(6):
+        if rs.rand() < prob[k]:
+            t = np.round(truncnorm.rvs(a=(lb[k] - mu[k]) / sd[k], b=(ub[k] - mu[k]) / sd[k], loc=mu[k],
+                                       scale=sd[k], random_state=rs))
+            times.append(float(t))
+            amounts.append(float(max(round(rs.normal(amu[k], asd[k])), 0)))
+    return times, amounts
+
+
+def random_scenario_cho(seed, start_minute_of_day, n_minutes):
+    """RandomScenario(start_time, seed) after reset(): per-minute announced CHO (scenario_gen.py:15-31).
+    A fresh day is drawn at reset and again whenever the clock reads 00:00 (quirk 4)."""
+    rs = np.random.RandomState(seed)
+    times, amounts = random_scenario_draw(rs)
+    cho = np.zeros(n_minutes)
+    for m in range(n_minutes):
+        tod = (start_minute_of_day + m) % 1440
+        if tod == 0:
+            times, amounts = random_scenario_draw(rs)
+        if float(tod) in times:
+            cho[m] = amounts[times.index(float(tod))]
+    return cho
