@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the fused T1D step on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over the batch = ONE kernel launch advancing every env by
+one simulated minute (1-min dt: Navigator-class sensor, sample_time = 1).  Workload at N = 1:
+BASELINE.json configs[3]'s batch -- 1 048 576 concurrent envs, patient = i mod 30, random-action
+policy (basal = U(0,2) x the patient's steady-state basal, from a pool of pre-generated action
+tensors resident in HBM), per-env random meal tables, fp64, RK4 n_sub = 4, Philox CGM noise.
+With --gpus N each rank owns its own 1 Mi envs (weak scaling; independent episodes, no data-path
+collective); value = all ranks' env-steps / max-over-ranks wall time.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {"f64": 352, "f32": 184}       # algorithmic HBM bytes per env-step
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n_envs, steps, n_sub, sensor):
+    """The CPU oracle (oracle/t1d_oracle.c, a from-scratch port of the reference path with the same
+    RK4 integrator) timed on one host core over a bounded sample of the same workload."""
+    from oracle import t1d_oracle as O
+    rs = np.random.RandomState(0)
+    pid = np.arange(n_envs) % 30
+    env = O.OracleEnv(pid, sensor=sensor, normals=rs.randn(64, n_envs), integrator="rk4", n_sub=n_sub)
+    env.reset()
+    names, tab = O.patient_table()
+    basal0 = tab[pid, O.IDX["u2ss"]] * tab[pid, O.IDX["BW"]] / 6000.0
+    acts = [basal0 * rs.uniform(0, 2, n_envs) for _ in range(4)]
+    cho = np.zeros((int(env.sample_time), n_envs))
+    env.step(acts[0], None, cho)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        cho[:] = 0.0
+        if k % 30 == 7:
+            cho[0, (np.arange(n_envs) + k) % 5 == 0] = 50.0
+        env.step(acts[k % 4], None, cho)
+    dt = time.perf_counter() - t0
+    return {"value": n_envs * steps * int(env.sample_time) / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d steps, RK4 n_sub=%d, fp64, 1 thread, %.1f s" % (n_envs, steps, n_sub, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
+    ap.add_argument("--n-sub", type=int, default=4)
+    ap.add_argument("--sensor", default="Navigator")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=65536)
+    ap.add_argument("--cpu-steps", type=int, default=60)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from simglucose_amd.batch_env import BatchedT1DSimEnv
+    from simglucose_amd import params, scenario_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus),
+              file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = a.envs
+    dt = torch.float64 if a.dtype == "f64" else torch.float32
+    names, tab = params.patient_table()
+    pid = np.arange(n, dtype=np.int64) % 30
+    env = BatchedT1DSimEnv(patient=pid, sensor=a.sensor, dtype=dt, device=dev, n_sub=a.n_sub, seed=1234,
+                           env_offset=rank * n, noise="philox", extra_outputs=False)
+    days = 1 + (a.steps + a.warmup) * env.minutes_per_step // 1440
+    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=0, seed=1000 + rank, device=dev, dtype=dt)
+    env.set_meals(mt, ma)
+    basal0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, dtype=dt, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(7 + rank)
+    pool = [(basal0 * 2.0 * torch.rand(n, generator=g, device=dev, dtype=dt)).contiguous() for _ in range(8)]
+    env.reset()
+    for k in range(a.warmup):
+        env.step(pool[k % 8])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        env.step(pool[k % 8])
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    status = env.sync(raise_on_status=False)
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    minutes = env.minutes_per_step
+    total_env_steps = world * n * a.steps * minutes
+    bg = env.bg
+    sane = bool(torch.isfinite(bg).all()) and status == 0
+
+    if rank == 0:
+        algo = ALGO_BYTES[a.dtype] * n * minutes          # algorithmic bytes per launch (per GPU)
+        ach = algo / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec at batch=1M patients (1-min dt)", "value": total_env_steps / wall,
+            "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "configs[3]: %d envs per GPU, patient=i mod 30, random-action policy, "
+                                   "random meal tables, %s sensor (sample_time %d min), RK4 n_sub=%d, Philox CGM noise"
+                                   % (n, a.sensor, minutes, a.n_sub),
+                       "envs_per_gpu": n, "n_sub": a.n_sub, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "step_kernel<%s>" % ("double" if a.dtype == "f64" else "float"),
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
+            "sane": sane, "status_bits": status,
+            "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_envs, a.cpu_steps, a.n_sub, a.sensor)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * t1d.h -- C ABI of libt1d_hip.so: the MI355X (gfx950) batched T1D glucose-insulin simulator.
+ *
+ * The reference (Sawyerbatch/simglucose, pure Python) has no FFI boundary; the boundary this
+ * library replaces is the Python call chain below, for a whole batch of environments at once
+ * (paths relative to the reference checkout):
+ *
+ *   t1d_reset        <- T1DSimEnv.reset / _reset        simglucose/simulation/env.py:119-155
+ *                       T1DPatient.reset                simglucose/patient/t1dpatient.py:247-281
+ *                       CGMSensor.reset / CGMNoise()    simglucose/sensor/cgm.py:47-50, noise_gen.py:15-28
+ *   t1d_step         <- T1DSimEnv.step / mini_step      simglucose/simulation/env.py:48-117
+ *                       InsulinPump.basal / .bolus      simglucose/actuator/pump.py:23-39
+ *                       T1DPatient.step / model         simglucose/patient/t1dpatient.py:82-208,222-236
+ *                       scipy ode('dopri5').integrate   simglucose/patient/t1dpatient.py:110-113,276
+ *                         (replaced by fixed-step RK4 with n_sub sub-steps per minute)
+ *                       CGMSensor.measure / CGMNoise    simglucose/sensor/cgm.py:26-36, noise_gen.py:30-97
+ *                       risk_index / risk_diff          simglucose/analysis/risk.py:5-17, env.py:27-33
+ *   t1d_rollout_pid  <- SimObj.simulate loop with       simglucose/simulation/sim_engine.py:29-39
+ *                       PIDController.policy            simglucose/controller/pid_ctrller.py:17-36
+ *
+ * Conventions
+ *  - Every pointer inside t1d_batch is a DEVICE pointer (e.g. torch.Tensor.data_ptr()) owned by
+ *    the caller, who keeps it alive until the stream has passed the call.  Arrays are struct-of-
+ *    arrays with the env index fastest: a [K][n] array holds element k of env i at k*n + i.
+ *    Floating arrays have the element type named by `dtype` (T1D_F64: double, T1D_F32: float).
+ *  - Calls only enqueue work on `hip_stream` (a hipStream_t; NULL = default stream); they never
+ *    synchronise.  Asynchronous faults surface at t1d_sync or the next call.
+ *  - Return value 0 = success; negative = error (see T1D_E_*), message in t1d_last_error()
+ *    (thread-local).  No C++ exception crosses this boundary.
+ *  - A ctx is bound to one device and is not thread-safe: one host thread/process per GPU.
+ */
+#ifndef T1D_H
+#define T1D_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T1D_ABI_VERSION 1
+
+enum { T1D_F64 = 0, T1D_F32 = 1 };
+
+enum {
+    T1D_OK = 0,
+    T1D_E_INVALID = -1,      /* bad argument (null pointer, size, dtype, n_sub ...) */
+    T1D_E_HIP = -2,          /* a HIP runtime call failed */
+    T1D_E_NODEVICE = -3,     /* no usable gfx950 device */
+    T1D_E_STATUS = -4        /* t1d_sync: a kernel raised a status bit (see T1D_ST_*) */
+};
+
+/* bits of the device status word returned through t1d_sync */
+enum {
+    T1D_ST_NORMALS_EXHAUSTED = 1,   /* host-normals mode ran past n_normals rows; zeros were used */
+    T1D_ST_NONFINITE = 2            /* some env's state became NaN/Inf */
+};
+
+/* columns of one row of the patient table given to t1d_ctx_create (all double):
+ * x0_1..x0_13 then the model parameters of params/vpatient_params.csv in this order. */
+enum {
+    T1D_P_X0 = 0,
+    T1D_P_BW = 13, T1D_P_KABS, T1D_P_KMAX, T1D_P_KMIN, T1D_P_B, T1D_P_D, T1D_P_VG, T1D_P_VI,
+    T1D_P_VMX, T1D_P_KM0, T1D_P_K2, T1D_P_K1, T1D_P_P2U, T1D_P_M1, T1D_P_M2, T1D_P_M4, T1D_P_M30,
+    T1D_P_IB, T1D_P_KI, T1D_P_KP2, T1D_P_KP3, T1D_P_F, T1D_P_KE1, T1D_P_KE2, T1D_P_FSNC,
+    T1D_P_VM0, T1D_P_KD, T1D_P_KSC, T1D_P_KA1, T1D_P_KA2, T1D_P_KP1, T1D_P_U2SS,
+    T1D_P_NCOLS                                          /* = 45 */
+};
+/* sensor row (params/sensor_params.csv): PACF, gamma, lambda, delta, xi, sample_time, min, max */
+#define T1D_SENSOR_NCOLS 8
+/* pump row (params/pump_params.csv): min_bolus, max_bolus, inc_bolus, min_basal, max_basal, inc_basal */
+#define T1D_PUMP_NCOLS 6
+
+/* per-env packed integer word `meta`: bits 0-7 patient row, bit 8 "was eating last minute"
+ * (t1dpatient.py:88,102 edge detector), bits 16-31 cursor into the meal table. */
+#define T1D_META_PID(m)      ((m) & 0xffu)
+#define T1D_META_EATING      0x100u
+#define T1D_META_CURSOR(m)   ((m) >> 16)
+
+typedef struct t1d_ctx t1d_ctx;
+
+typedef struct t1d_batch {
+    int64_t n;                /* envs in this batch (this GPU's shard) */
+    int64_t env_offset;       /* global index of env 0: Philox subsequence = env_offset + i */
+    int32_t dtype;            /* T1D_F64 | T1D_F32 */
+    int32_t n_meals;          /* rows of the meal table (0 = none) */
+    int32_t n_normals;        /* rows of `normals` (0 = draw in-kernel with Philox) */
+    int32_t reserved;
+    uint64_t seed;            /* Philox key */
+    /* ---- state (read + written by t1d_step; written by t1d_reset) */
+    void* x;                  /* [13][n] ODE state */
+    void* planned;            /* [n] planned_meal, g        (t1dpatient.py:229) */
+    void* last_qsto;          /* [n] mg                     (t1dpatient.py:90)  */
+    void* last_food;          /* [n] g                      (t1dpatient.py:99)  */
+    int32_t* t;               /* [n] minutes since episode start */
+    uint32_t* meta;           /* [n] packed: patient row | eating flag | meal cursor */
+    uint32_t* episode;        /* [n] episode counter, pre-incremented by t1d_reset; separates the Philox
+                                 streams of successive episodes of one env.  NULL = always 0 */
+    void* last_cgm;           /* [n] sensor zero-order hold (cgm.py:32-36) */
+    void* ar_e;               /* [n] AR(1) noise state      (noise_gen.py:86-88) */
+    void* pts;                /* [11][n] Johnson-SU points of the current 150-min block */
+    void* prev_cgm;           /* [n] CGM_hist[-1] (default reward, env.py:27-33) */
+    /* ---- inputs */
+    const void* basal;        /* [n] U/min */
+    const void* bolus;        /* [n] U/min, NULL = 0 */
+    const void* cho;          /* [minutes][n] announced grams per minute, NULL = use meal table */
+    const int32_t* meal_time; /* [n_meals][n] minute since episode start, ascending per env;
+                                 unused slots = INT32_MAX; at most one entry per minute */
+    const void* meal_amt;     /* [n_meals][n] grams */
+    const void* normals;      /* [n_normals][n] standard normals in draw order (exact-parity mode) */
+    const void* x0_override;  /* [13][n] initial state for t1d_reset, NULL = table x0 */
+    /* ---- outputs (any of lbgi..insulin may be NULL) */
+    void* cgm;                /* [n] observation: mean CGM over the step (env.py:81) */
+    void* bg;                 /* [n] mean Gsub over the step (env.py:80) */
+    void* reward;             /* [n] risk_diff */
+    uint8_t* done;            /* [n] bg < 70 or bg > 350 */
+    void* lbgi; void* hbgi; void* risk;   /* [n] risk_index([bg], 1) */
+    void* meal;               /* [n] mean announced CHO (env.py:78) */
+    void* insulin;            /* [n] mean pump output (env.py:79) */
+} t1d_batch;
+
+typedef struct t1d_pid {
+    double P, I, D, target;   /* controller/pid_ctrller.py:7-15 */
+    void* integ;              /* [n] integrated_state */
+    void* prev;               /* [n] prev_state */
+    /* optional per-env accumulators over the roll-out (NULL to skip) */
+    void* sum_risk;           /* [n] += risk each step */
+    void* min_bg; void* max_bg;   /* [n] */
+    int32_t* n_low;           /* [n] += (bg < 70)  per step */
+    int32_t* n_high;          /* [n] += (bg > 180) per step */
+} t1d_pid;
+
+int t1d_abi_version(void);
+const char* t1d_last_error(void);
+
+/* Build the constant tables of one device.  patient_table: [n_patients][n_cols] (T1D_P_* order,
+ * n_cols == T1D_P_NCOLS), sensor_row [T1D_SENSOR_NCOLS], pump_row [T1D_PUMP_NCOLS], spline_W
+ * [w_rows][11] = the cubic-spline block operator of the CGM noise (noise_gen.py:45-47), all host
+ * doubles, copied.  sample_time must be a positive integer number of minutes. */
+int t1d_ctx_create(int hip_device, const double* patient_table, int n_patients, int n_cols,
+                   const double* sensor_row, const double* pump_row, const double* spline_W,
+                   int w_rows, t1d_ctx** out);
+int t1d_ctx_destroy(t1d_ctx* ctx);
+
+/* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after
+ * T1DSimEnv.reset(): cgm = CGM sample #1, prev_cgm = CGM sample #0, bg/lbgi/hbgi/risk of the
+ * initial state, reward 0, done 0.  random_init_bg != 0 draws x[3], x[4], x[12] ~ N(mu, 0.1 mu)
+ * with Philox (statistical counterpart of t1dpatient.py:256-270; exact parity = x0_override). */
+int t1d_reset(t1d_ctx* ctx, const t1d_batch* b, const uint8_t* mask, int random_init_bg, void* hip_stream);
+
+/* Advance every env by `minutes` (normally int(sample_time)) with one kernel launch, the same
+ * action held for the whole call, RK4 with n_sub sub-steps per minute. */
+int t1d_step(t1d_ctx* ctx, const t1d_batch* b, int minutes, int n_sub, void* hip_stream);
+
+/* n_steps closed-loop steps in ONE launch: basal = PID(obs CGM), bolus = 0, then as t1d_step.
+ * b->cgm must hold the current observation on entry (as left by t1d_reset / t1d_step). */
+int t1d_rollout_pid(t1d_ctx* ctx, const t1d_batch* b, const t1d_pid* pid, int n_steps, int minutes,
+                    int n_sub, void* hip_stream);
+
+/* The standard normals the kernels draw in Philox mode for episode `episode`: out[r][i] = draw
+ * (draw0 + r) of env (env_offset + i), doubles [n_draws][n] on the device.  Draw 0 is the AR(1)
+ * initial value, draws 1.. are the block normals in consumption order (so the array can be fed
+ * back as `normals`); draws -3..-1 are the three random_init_bg normals (x[3], x[4], x[12]).
+ * Lets a test replay a Philox run through the oracle. */
+int t1d_philox_normals(t1d_ctx* ctx, uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,
+                       int32_t draw0, int32_t n_draws, double* out_device, void* hip_stream);
+
+/* Wait for the stream and return the accumulated status bits through *status (then clear them). */
+int t1d_sync(t1d_ctx* ctx, void* hip_stream, int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T1D_H */

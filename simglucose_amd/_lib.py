@@ -1,0 +1,102 @@
+"""ctypes binding of libt1d_hip.so (include/t1d.h).  There is no CPU fallback: if the HIP
+library is missing or fails to load, every product path raises."""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libt1d_hip.so")
+SOURCES = [os.path.join(_PKG, "csrc", "t1d_abi.hip"), os.path.join(_PKG, "csrc", "t1d_device.hpp"),
+           os.path.join(_ROOT, "include", "t1d.h")]
+
+T1D_F64, T1D_F32 = 0, 1
+T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE = 1, 2
+P_NCOLS = 45
+MEAL_UNUSED = 0x7FFFFFFF
+META_EATING = 0x100
+
+EXPORTS = ("t1d_abi_version", "t1d_last_error", "t1d_ctx_create", "t1d_ctx_destroy", "t1d_reset",
+           "t1d_step", "t1d_rollout_pid", "t1d_philox_normals", "t1d_sync")
+
+
+class T1DError(RuntimeError):
+    pass
+
+
+class Batch(C.Structure):
+    """struct t1d_batch (include/t1d.h)"""
+    _fields_ = [
+        ("n", C.c_int64), ("env_offset", C.c_int64), ("dtype", C.c_int32), ("n_meals", C.c_int32),
+        ("n_normals", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
+        ("x", C.c_void_p), ("planned", C.c_void_p), ("last_qsto", C.c_void_p), ("last_food", C.c_void_p),
+        ("t", C.c_void_p), ("meta", C.c_void_p), ("episode", C.c_void_p),
+        ("last_cgm", C.c_void_p), ("ar_e", C.c_void_p), ("pts", C.c_void_p), ("prev_cgm", C.c_void_p),
+        ("basal", C.c_void_p), ("bolus", C.c_void_p), ("cho", C.c_void_p), ("meal_time", C.c_void_p),
+        ("meal_amt", C.c_void_p), ("normals", C.c_void_p), ("x0_override", C.c_void_p),
+        ("cgm", C.c_void_p), ("bg", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+        ("lbgi", C.c_void_p), ("hbgi", C.c_void_p), ("risk", C.c_void_p), ("meal", C.c_void_p),
+        ("insulin", C.c_void_p),
+    ]
+
+
+class Pid(C.Structure):
+    """struct t1d_pid (include/t1d.h)"""
+    _fields_ = [("P", C.c_double), ("I", C.c_double), ("D", C.c_double), ("target", C.c_double),
+                ("integ", C.c_void_p), ("prev", C.c_void_p), ("sum_risk", C.c_void_p),
+                ("min_bg", C.c_void_p), ("max_bg", C.c_void_p), ("n_low", C.c_void_p), ("n_high", C.c_void_p)]
+
+
+def build(force=False, verbose=False):
+    """Compile libt1d_hip.so for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in SOURCES)
+    if stale:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-o", LIB_PATH, SOURCES[0]]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (building it first if the sources are newer).  Raises T1DError when
+    it cannot be produced or loaded -- the product never falls back to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        if not os.path.exists(LIB_PATH) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH)
+                                               for s in SOURCES):
+            build()
+        L = C.CDLL(LIB_PATH)
+    except (OSError, subprocess.CalledProcessError, FileNotFoundError) as e:
+        raise T1DError("libt1d_hip.so (HIP/gfx950 extension) is not available: %s" % e) from e
+    vp, i32, i64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
+    dp = C.POINTER(C.c_double)
+    L.t1d_abi_version.restype = C.c_int
+    L.t1d_last_error.restype = C.c_char_p
+    L.t1d_ctx_create.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.POINTER(vp)]
+    L.t1d_ctx_destroy.argtypes = [vp]
+    L.t1d_reset.argtypes = [vp, C.POINTER(Batch), vp, C.c_int, vp]
+    L.t1d_step.argtypes = [vp, C.POINTER(Batch), C.c_int, C.c_int, vp]
+    L.t1d_rollout_pid.argtypes = [vp, C.POINTER(Batch), C.POINTER(Pid), C.c_int, C.c_int, C.c_int, vp]
+    L.t1d_philox_normals.argtypes = [vp, u64, i64, i64, u32, i32, i32, vp, vp]
+    L.t1d_sync.argtypes = [vp, vp, C.POINTER(i32)]
+    for name in EXPORTS:
+        if name not in ("t1d_last_error",):
+            getattr(L, name).restype = C.c_int
+    if L.t1d_abi_version() != 1:
+        raise T1DError("libt1d_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise T1DError("t1d error %d: %s" % (rc, lib().t1d_last_error().decode()))

@@ -1,0 +1,243 @@
+"""BatchedT1DSimEnv: N independent T1DSimEnv episodes advanced by one HIP kernel launch per step.
+
+The host side holds the batched state as struct-of-arrays PyTorch-ROCm tensors (env index fastest)
+and hands their device pointers to libt1d_hip.so through the C ABI of include/t1d.h.  Semantics per
+env are those of the reference's ``simglucose/simulation/env.py`` ``T1DSimEnv.reset/step`` composed
+of ``T1DPatient`` + ``CGMSensor`` + ``InsulinPump`` + a meal scenario; the ODE integrator is
+fixed-step RK4 (``n_sub`` sub-steps per minute) instead of SciPy's adaptive DOPRI5.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, params
+
+_STATE_KEYS = ("x", "planned", "last_qsto", "last_food", "t", "meta", "episode", "last_cgm", "ar_e", "pts",
+               "prev_cgm")
+_OUT_KEYS = ("cgm", "bg", "reward", "done", "lbgi", "hbgi", "risk", "meal", "insulin")
+
+
+class BatchedT1DSimEnv:
+    """A batch of ``n`` glucose-insulin simulation environments on one MI355X.
+
+    patient: one name, a list of names (len n) or an integer array of table rows (len n).
+    sensor / pump: hardware names from the parameter tables (one per batch).
+    noise: "philox" draws the CGM noise normals in-kernel (rocRAND Philox4x32-10, stream =
+           global env id); "host" reads them from ``normals[n_draws, n]`` (exact parity with
+           ``numpy.random.RandomState(seed).randn()`` streams supplied by the caller).
+    """
+
+    def __init__(self, patient="adolescent#001", n_envs=None, sensor="Dexcom", pump="Insulet",
+                 dtype=torch.float64, device="cuda:0", n_sub=4, seed=0, env_offset=0, noise="philox",
+                 normals=None, random_init_bg=False, extra_outputs=True, sensor_row=None, pump_row=None):
+        self._L = _lib.lib()                     # raises T1DError if the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise _lib.T1DError("BatchedT1DSimEnv needs a ROCm GPU (torch.cuda.is_available() is False)")
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.n_sub = int(n_sub)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.env_offset = int(env_offset)
+        self.random_init_bg = bool(random_init_bg)
+        self.names, self.table = params.patient_table()
+        if isinstance(patient, str):
+            if n_envs is None:
+                n_envs = 1
+            pid = np.full(int(n_envs), params.patient_index(patient), dtype=np.int64)
+        else:
+            arr = list(patient) if not isinstance(patient, (np.ndarray, torch.Tensor)) else patient
+            if len(arr) and isinstance(arr[0], str):
+                pid = np.array([params.patient_index(p) for p in arr], dtype=np.int64)
+            else:
+                pid = np.asarray(torch.as_tensor(arr).cpu().numpy(), dtype=np.int64)
+            if n_envs is not None and int(n_envs) != len(pid):
+                raise ValueError("n_envs does not match the patient list")
+        if pid.size < 1 or pid.min() < 0 or pid.max() >= len(self.names):
+            raise ValueError("patient index out of range")
+        self.n = int(pid.size)
+        self.patient_idx = pid
+        self.sensor_name, self.pump_name = sensor, pump
+        self.sensor_row = np.asarray(sensor_row if sensor_row is not None else params.sensor_row(sensor), dtype=np.float64)
+        self.pump_row = np.asarray(pump_row if pump_row is not None else params.pump_row(pump), dtype=np.float64)
+        self.sample_time = float(self.sensor_row[5])
+        self.minutes_per_step = int(self.sample_time)
+        self.W = np.ascontiguousarray(params.spline_block_operator(self.sample_time))
+
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._ctx = C.c_void_p()
+        dp = C.POINTER(C.c_double)
+        tab = np.ascontiguousarray(self.table)
+        _lib.check(self._L.t1d_ctx_create(dev_index, tab.ctypes.data_as(dp), tab.shape[0], tab.shape[1],
+                                          self.sensor_row.ctypes.data_as(dp), self.pump_row.ctypes.data_as(dp),
+                                          self.W.ctypes.data_as(dp), self.W.shape[0], C.byref(self._ctx)))
+        n, dv, ft = self.n, self.device, dtype
+        z = lambda *shape, dt=ft: torch.zeros(*shape, dtype=dt, device=dv)
+        self.x = z(13, n); self.planned = z(n); self.last_qsto = z(n); self.last_food = z(n)
+        self.t = z(n, dt=torch.int32)
+        self.meta = torch.from_numpy(pid.astype(np.int32)).to(dv)          # patient row in bits 0-7
+        self.episode = z(n, dt=torch.int32)
+        self.last_cgm = z(n); self.ar_e = z(n); self.pts = z(11, n); self.prev_cgm = z(n)
+        self.cgm = z(n); self.bg = z(n); self.reward = z(n); self.done = z(n, dt=torch.uint8)
+        if extra_outputs:
+            self.lbgi = z(n); self.hbgi = z(n); self.risk = z(n); self.meal = z(n); self.insulin = z(n)
+        else:
+            self.lbgi = self.hbgi = self.risk = self.meal = self.insulin = None
+        self._zero_action = z(n)
+        self._basal_buf = z(n); self._bolus_buf = z(n)
+        self.meal_time = None; self.meal_amt = None
+        self.normals = None
+        self._b = _lib.Batch()
+        b = self._b
+        b.n, b.env_offset, b.dtype, b.seed = n, self.env_offset, (_lib.T1D_F64 if ft == torch.float64 else _lib.T1D_F32), self.seed
+        for k in _STATE_KEYS + _OUT_KEYS:
+            tns = getattr(self, k)
+            setattr(b, k, tns.data_ptr() if tns is not None else None)
+        b.n_meals = 0; b.n_normals = 0
+        if noise not in ("philox", "host"):
+            raise ValueError("noise must be 'philox' or 'host'")
+        self.noise = noise
+        if noise == "host":
+            if normals is None:
+                raise ValueError("noise='host' needs normals[n_draws, n]")
+            self.set_normals(normals)
+        self._closed = False
+
+    # ------------------------------------------------------------------ inputs
+    def _as_input(self, v, buf):
+        """-> a contiguous [n] tensor of the env dtype on the env device (copying only if needed)."""
+        if isinstance(v, torch.Tensor) and v.dtype == self.dtype and v.device == self.device and v.shape == (self.n,) \
+                and v.is_contiguous():
+            return v
+        buf.copy_(torch.as_tensor(v, dtype=self.dtype, device=self.device).expand(self.n))
+        return buf
+
+    def set_normals(self, normals):
+        """Host-supplied standard normals [n_draws, n]: row 0 seeds the AR(1) state, rows 1.. are
+        consumed ten per 150-minute noise block (noise_gen.py:84-97)."""
+        t = torch.as_tensor(normals, dtype=self.dtype).to(self.device).contiguous()
+        if t.dim() != 2 or t.shape[1] != self.n:
+            raise ValueError("normals must have shape [n_draws, n]")
+        self.normals = t
+        self._b.normals = t.data_ptr(); self._b.n_normals = t.shape[0]
+        self.noise = "host"
+
+    def set_meals(self, meal_time, meal_amt):
+        """Per-env meal table: meal_time[m, i] = minute since episode start (ascending per env,
+        unused = MEAL_UNUSED), meal_amt[m, i] = grams announced at that minute."""
+        mt = torch.as_tensor(meal_time).to(torch.int32).to(self.device).contiguous()
+        ma = torch.as_tensor(meal_amt).to(self.dtype).to(self.device).contiguous()
+        if mt.dim() != 2 or mt.shape != ma.shape or mt.shape[1] != self.n:
+            raise ValueError("meal tables must both have shape [n_meals, n]")
+        self.meal_time, self.meal_amt = mt, ma
+        self._b.meal_time, self._b.meal_amt, self._b.n_meals = mt.data_ptr(), ma.data_ptr(), mt.shape[0]
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, mask=None, x0=None):
+        """T1DSimEnv.reset() on every env (or those with mask != 0).  -> observation CGM [n]."""
+        b = self._b
+        keep = None
+        if x0 is not None:
+            keep = torch.as_tensor(x0, dtype=self.dtype).to(self.device).contiguous()
+            if keep.shape != (13, self.n):
+                raise ValueError("x0 must have shape [13, n]")
+            b.x0_override = keep.data_ptr()
+        else:
+            b.x0_override = None
+        mptr = None
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(self.device).to(torch.uint8).contiguous()
+            mptr = C.c_void_p(mask.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.t1d_reset(self._ctx, C.byref(b), mptr, int(self.random_init_bg), self._stream()))
+        b.x0_override = None
+        self._keep = (keep, mask)
+        return self.cgm
+
+    def step(self, basal, bolus=None, cho=None, minutes=None):
+        """One env.step for the whole batch: a single kernel launch advancing ``minutes``
+        (default int(sample_time)) with the action held.  -> (obs CGM [n], reward [n], done [n], info)."""
+        b = self._b
+        minutes = self.minutes_per_step if minutes is None else int(minutes)
+        bas = self._as_input(basal, self._basal_buf)
+        b.basal = bas.data_ptr()
+        if bolus is None:
+            b.bolus = None
+        else:
+            b.bolus = self._as_input(bolus, self._bolus_buf).data_ptr()
+        if cho is not None:
+            cho = torch.as_tensor(cho, dtype=self.dtype).to(self.device).contiguous()
+            if cho.shape != (minutes, self.n):
+                raise ValueError("cho must have shape [minutes, n]")
+            b.cho = cho.data_ptr()
+        else:
+            b.cho = None
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.t1d_step(self._ctx, C.byref(b), minutes, self.n_sub, self._stream()))
+        self._keep = (bas, cho)
+        return self.cgm, self.reward, self.done, self.info()
+
+    def info(self):
+        return {"sample_time": self.sample_time, "bg": self.bg, "lbgi": self.lbgi, "hbgi": self.hbgi,
+                "risk": self.risk, "meal": self.meal, "insulin": self.insulin, "patient_state": self.x,
+                "t": self.t}
+
+    def rollout_pid(self, n_steps, P, I, D, target=140.0, pid_state=None, stats=None):
+        """n_steps closed-loop PID steps in one launch (PIDController.policy + env.step per step).
+        pid_state: dict(integ, prev) tensors [n] (created zeroed if None).  stats: optional dict
+        with any of sum_risk, min_bg, max_bg (float [n]) and n_low, n_high (int32 [n])."""
+        if pid_state is None:
+            pid_state = {"integ": torch.zeros(self.n, dtype=self.dtype, device=self.device),
+                         "prev": torch.zeros(self.n, dtype=self.dtype, device=self.device)}
+        p = _lib.Pid()
+        p.P, p.I, p.D, p.target = float(P), float(I), float(D), float(target)
+        p.integ, p.prev = pid_state["integ"].data_ptr(), pid_state["prev"].data_ptr()
+        stats = stats or {}
+        for k in ("sum_risk", "min_bg", "max_bg", "n_low", "n_high"):
+            setattr(p, k, stats[k].data_ptr() if k in stats else None)
+        self._b.cho = None
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.t1d_rollout_pid(self._ctx, C.byref(self._b), C.byref(p), int(n_steps),
+                                               self.minutes_per_step, self.n_sub, self._stream()))
+        return pid_state
+
+    def philox_normals(self, n_draws, draw0=0, episode=1):
+        """The normals the kernels draw in Philox mode -> float64 [n_draws, n] (for replay tests)."""
+        out = torch.empty(n_draws, self.n, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.t1d_philox_normals(self._ctx, self.seed, self.env_offset, self.n, int(episode),
+                                                  int(draw0), int(n_draws), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def sync(self, raise_on_status=True):
+        """Wait for the stream; -> status bits (T1D_ST_*)."""
+        st = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            rc = self._L.t1d_sync(self._ctx, self._stream(), C.byref(st))
+        if rc != 0 and (raise_on_status or st.value == 0):
+            _lib.check(rc)
+        return st.value
+
+    # ------------------------------------------------------------------ checkpoint
+    def state_dict(self):
+        return {k: getattr(self, k).clone() for k in _STATE_KEYS + ("cgm",)}
+
+    def load_state_dict(self, sd):
+        for k in _STATE_KEYS + ("cgm",):
+            getattr(self, k).copy_(sd[k])
+
+    def close(self):
+        if not self._closed and self._ctx:
+            self._L.t1d_ctx_destroy(self._ctx)
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

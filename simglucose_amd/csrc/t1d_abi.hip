@@ -1,0 +1,590 @@
+// t1d_abi.hip -- kernels and C ABI of libt1d_hip.so (gfx950 only; see include/t1d.h).
+//
+// Kernels
+//   step_kernel<T>     one launch per env.step: pump -> [meal bookkeeping -> RK4 x n_sub -> Gsub ->
+//                      CGM sample/hold] x minutes -> risk/reward/done.      (env.py:48-117)
+//   reset_kernel<T>    masked T1DSimEnv.reset().                            (env.py:119-155)
+//   rollout_pid_kernel<T>  n_steps x (PID policy + step) with state in registers.
+//   philox_normals_kernel  replays the Philox stream for tests.
+#include "../../include/t1d.h"
+#include "t1d_device.hpp"
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace t1d {
+
+template <typename T> struct KArgs {
+    int64_t n, env_offset;
+    uint64_t seed;
+    T* x; T* planned; T* last_qsto; T* last_food; int32_t* t; uint32_t* meta; uint32_t* episode;
+    T* last_cgm; T* ar_e; T* pts; T* prev_cgm;
+    const T* basal; const T* bolus; const T* cho; const int32_t* meal_time; const T* meal_amt;
+    const T* normals; const T* x0_override;
+    T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin;
+    const T* dpar;          // [DP_COUNT][np] derived patient constants
+    const double* x0tab;    // [13][np]
+    const T* W;             // [S][11]
+    int* status;
+    SensorC<T> sen; PumpC<T> pump;
+    int np, S, n_meals, n_normals, minutes, n_sub;
+};
+
+template <typename T> struct PidArgs {
+    T P, I, D, target;
+    T* integ; T* prev; T* sum_risk; T* min_bg; T* max_bg; int32_t* n_low; int32_t* n_high;
+    int n_steps;
+};
+
+// env state held in registers across the minutes of a launch
+template <typename T> struct Env {
+    T x[13];
+    T planned, lq, lf, last_cgm, ar_e, prev_cgm;
+    int t, cursor;
+    bool eating;
+};
+template <typename T> struct StepOut { T cgm, bg, meal, ins; };
+
+template <typename T>
+__device__ __forceinline__ void stage_pars(const KArgs<T>& a, T* lds)
+{
+    const int tot = DP_COUNT * a.np;
+    for (int j = threadIdx.x; j < tot; j += blockDim.x) lds[j] = a.dpar[j];
+    __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void load_env(const KArgs<T>& a, int64_t i, uint32_t meta, Env<T>& e)
+{
+    const int64_t n = a.n;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) e.x[k] = a.x[k * n + i];
+    e.planned = a.planned[i]; e.lq = a.last_qsto[i]; e.lf = a.last_food[i];
+    e.last_cgm = a.last_cgm[i]; e.ar_e = a.ar_e[i]; e.prev_cgm = a.prev_cgm[i];
+    e.t = a.t[i];
+    e.eating = (meta & T1D_META_EATING) != 0;
+    e.cursor = (int)T1D_META_CURSOR(meta);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_env(const KArgs<T>& a, int64_t i, uint32_t pid, const Env<T>& e)
+{
+    const int64_t n = a.n;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) a.x[k * n + i] = e.x[k];
+    a.planned[i] = e.planned; a.last_qsto[i] = e.lq; a.last_food[i] = e.lf;
+    a.last_cgm[i] = e.last_cgm; a.ar_e[i] = e.ar_e; a.prev_cgm[i] = e.prev_cgm;
+    a.t[i] = e.t;
+    a.meta[i] = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+}
+
+// next(CGMNoise) for sample index s (noise_gen.py:61-69; refill :30-56; AR(1) source :84-97).
+template <typename T>
+__device__ __forceinline__ T noise_sample(const KArgs<T>& a, int64_t i, int s, T& ar_e)
+{
+    const int64_t n = a.n;
+    const int j = s % a.S, b = s / a.S;
+    const T* w = a.W + j * 11;
+    T acc;
+    if (j == 0) {                       // deque empty: build the next 150-minute block
+        T p[11];
+        p[0] = a.pts[(b > 0 ? 10 : 0) * n + i];     // carried-over last point (:33,36)
+        T z[10];
+        if (a.normals) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const int d = 1 + 10 * b + k;
+                if (d < a.n_normals) z[k] = a.normals[(int64_t)d * n + i];
+                else { z[k] = T(0); atomicOr(a.status, T1D_ST_NORMALS_EXHAUSTED); }
+            }
+        } else {
+            const uint32_t ep = a.episode ? a.episode[i] : 0u;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const double2 r = philox_pair(a.seed, (uint64_t)(a.env_offset + i), ep, 3u + 5u * (uint32_t)b + q);
+                z[2 * q] = (T)r.x; z[2 * q + 1] = (T)r.y;
+            }
+        }
+        T e = ar_e;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            e = a.sen.pacf * (e + z[k]);                // :88
+            p[k + 1] = johnson_su(a.sen, e);
+        }
+        ar_e = e;
+        acc = T(0);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { a.pts[k * n + i] = p[k]; acc += w[k] * p[k]; }
+    } else {
+        acc = T(0);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc += w[k] * a.pts[k * n + i];
+    }
+    return acc;
+}
+
+// CGMSensor.measure at patient time e.t (cgm.py:26-36); sample index = 1 + t/st after reset used #0,#1.
+template <typename T>
+__device__ __forceinline__ T measure(const KArgs<T>& a, int64_t i, Env<T>& e, T gsub)
+{
+    if (e.t % a.sen.st == 0) {
+        T cgm = gsub + noise_sample(a, i, 1 + e.t / a.sen.st, e.ar_e);
+        cgm = cgm > a.sen.vmin ? cgm : a.sen.vmin;
+        cgm = cgm < a.sen.vmax ? cgm : a.sen.vmax;
+        e.last_cgm = cgm;
+    }
+    return e.last_cgm;
+}
+
+// scenario.get_action(time) from the per-env meal table (scenario.py:33-42 / scenario_gen.py:23-31)
+template <typename T>
+__device__ __forceinline__ T meal_lookup(const KArgs<T>& a, int64_t i, Env<T>& e)
+{
+    T meal = T(0);
+    if (e.cursor < a.n_meals) {
+        int mt = a.meal_time[(int64_t)e.cursor * a.n + i];
+        while (mt < e.t && ++e.cursor < a.n_meals) mt = a.meal_time[(int64_t)e.cursor * a.n + i];
+        if (e.cursor < a.n_meals && mt == e.t) {
+            meal = a.meal_amt[(int64_t)e.cursor * a.n + i];
+            ++e.cursor;
+        }
+    }
+    return meal;
+}
+
+// T1DSimEnv.step body (env.py:66-84): `minutes` mini_steps with one action.
+template <typename T>
+__device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, const Pars<T>& p, int64_t i, Env<T>& e,
+                                                T basal, T bolus)
+{
+    const T q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
+    const T q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
+    const T insulin = q_basal + q_bolus;
+    const T div = T(a.minutes);
+    StepOut<T> o{T(0), T(0), T(0), T(0)};
+    for (int m = 0; m < a.minutes; ++m) {
+        const T meal = a.cho ? a.cho[(int64_t)m * a.n + i] : meal_lookup(a, i, e);      // env.py:50
+        const MinuteIn<T> u = eat_minute(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+        rk4_minute(p, u, e.x, a.n_sub);
+        e.t += 1;
+        const T gsub = e.x[12] / p.vg;                   // t1dpatient.py:217-218
+        const T cgm = measure(a, i, e, gsub);            // env.py:62
+        o.meal += meal / div; o.ins += insulin / div; o.bg += gsub / div; o.cgm += cgm / div;   // env.py:78-81
+    }
+    return o;
+}
+
+template <typename T>
+__device__ __forceinline__ void write_outputs(const KArgs<T>& a, int64_t i, Env<T>& e, const StepOut<T>& o)
+{
+    T l, h, r, rp, rc;
+    risk_index1(e.prev_cgm, l, h, rp);                    // risk_diff, env.py:27-33
+    risk_index1(o.cgm, l, h, rc);
+    a.reward[i] = rp - rc;
+    e.prev_cgm = o.cgm;
+    risk_index1(o.bg, l, h, r);                           // env.py:85
+    a.cgm[i] = o.cgm; a.bg[i] = o.bg;
+    a.done[i] = (o.bg < T(70) || o.bg > T(350)) ? 1 : 0;  // env.py:103
+    if (a.lbgi) a.lbgi[i] = l;
+    if (a.hbgi) a.hbgi[i] = h;
+    if (a.risk) a.risk[i] = r;
+    if (a.meal) a.meal[i] = o.meal;
+    if (a.insulin) a.insulin[i] = o.ins;
+    if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void step_kernel(const KArgs<T> a)
+{
+    __shared__ T lds[DP_COUNT * kMaxPatients];
+    stage_pars(a, lds);
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t meta = a.meta[i];
+    const uint32_t pid = T1D_META_PID(meta);
+    const Pars<T> p = load_pars(lds, a.np, (int)pid);
+    Env<T> e;
+    load_env(a, i, meta, e);
+    const T basal = a.basal[i];
+    const T bolus = a.bolus ? a.bolus[i] : T(0);
+    const StepOut<T> o = step_body(a, p, i, e, basal, bolus);
+    write_outputs(a, i, e, o);
+    store_env(a, i, pid, e);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rollout_pid_kernel(const KArgs<T> a, const PidArgs<T> c)
+{
+    __shared__ T lds[DP_COUNT * kMaxPatients];
+    stage_pars(a, lds);
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t meta = a.meta[i];
+    const uint32_t pid = T1D_META_PID(meta);
+    const Pars<T> p = load_pars(lds, a.np, (int)pid);
+    Env<T> e;
+    load_env(a, i, meta, e);
+    T obs = a.cgm[i];
+    T integ = c.integ[i], prev = c.prev[i];
+    T sum_risk = c.sum_risk ? c.sum_risk[i] : T(0);
+    T min_bg = c.min_bg ? c.min_bg[i] : T(0), max_bg = c.max_bg ? c.max_bg[i] : T(0);
+    int n_low = c.n_low ? c.n_low[i] : 0, n_high = c.n_high ? c.n_high[i] : 0;
+    const T st = T(a.sen.st);
+    StepOut<T> o{obs, T(0), T(0), T(0)};
+    T pre_prev_cgm = e.prev_cgm;
+    for (int s = 0; s < c.n_steps; ++s) {
+        // PIDController.policy (pid_ctrller.py:17-36)
+        const T u = c.P * (obs - c.target) + c.I * integ + c.D * (obs - prev) / st;
+        prev = obs;
+        integ += (obs - c.target) * st;
+        o = step_body(a, p, i, e, u, T(0));
+        obs = o.cgm;
+        pre_prev_cgm = e.prev_cgm;
+        e.prev_cgm = o.cgm;                      // CGM history advances every step
+        T l, h, r;
+        risk_index1(o.bg, l, h, r);
+        sum_risk += r;
+        min_bg = o.bg < min_bg ? o.bg : min_bg;
+        max_bg = o.bg > max_bg ? o.bg : max_bg;
+        n_low += o.bg < T(70); n_high += o.bg > T(180);
+    }
+    e.prev_cgm = pre_prev_cgm;                   // write_outputs forms the last step's reward from it
+    write_outputs(a, i, e, o);
+    store_env(a, i, pid, e);
+    c.integ[i] = integ; c.prev[i] = prev;
+    if (c.sum_risk) c.sum_risk[i] = sum_risk;
+    if (c.min_bg) c.min_bg[i] = min_bg;
+    if (c.max_bg) c.max_bg[i] = max_bg;
+    if (c.n_low) c.n_low[i] = n_low;
+    if (c.n_high) c.n_high[i] = n_high;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const uint8_t* mask, int random_init_bg)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    if (mask && !mask[i]) return;
+    const int64_t n = a.n;
+    const uint32_t pid = T1D_META_PID(a.meta[i]);
+    uint32_t ep = 0;
+    if (a.episode) { ep = a.episode[i] + 1u; a.episode[i] = ep; }
+    const uint64_t gid = (uint64_t)(a.env_offset + i);
+    Env<T> e;
+    // T1DPatient.reset (t1dpatient.py:247-281)
+#pragma unroll
+    for (int k = 0; k < 13; ++k)
+        e.x[k] = a.x0_override ? a.x0_override[k * n + i] : (T)a.x0tab[k * a.np + pid];
+    if (random_init_bg && !a.x0_override) {          // :256-270, statistical counterpart
+        const double2 r1 = philox_pair(a.seed, gid, ep, 1u), r2 = philox_pair(a.seed, gid, ep, 2u);
+        e.x[3] += t_sqrt(T(0.1) * e.x[3]) * (T)r1.x;
+        e.x[4] += t_sqrt(T(0.1) * e.x[4]) * (T)r1.y;
+        e.x[12] += t_sqrt(T(0.1) * e.x[12]) * (T)r2.x;
+    }
+    e.planned = T(0); e.lq = e.x[0] + e.x[1]; e.lf = T(0); e.eating = false; e.cursor = 0; e.t = 0;
+    // CGMSensor.reset -> CGMNoise(): first AR value and first 15-min point (noise_gen.py:24,86)
+    T z0;
+    if (a.normals) {
+        if (a.n_normals > 0) z0 = a.normals[i]; else { z0 = T(0); atomicOr(a.status, T1D_ST_NORMALS_EXHAUSTED); }
+    } else {
+        z0 = (T)philox_pair(a.seed, gid, ep, 0u).x;
+    }
+    e.ar_e = z0;
+    a.pts[i] = johnson_su(a.sen, z0);
+    e.last_cgm = T(0);
+    const T vg = a.dpar[DP_VG * a.np + pid];
+    const T bg0 = e.x[12] / vg;
+    T c[2];
+    for (int s = 0; s < 2; ++s) {                    // env.py:126 (history[0]) and env.py:142 (observation)
+        T v = bg0 + noise_sample(a, i, s, e.ar_e);
+        v = v > a.sen.vmin ? v : a.sen.vmin;
+        v = v < a.sen.vmax ? v : a.sen.vmax;
+        c[s] = v;
+    }
+    e.last_cgm = c[1];
+    e.prev_cgm = c[0];
+    store_env(a, i, pid, e);
+    T l, h, r;
+    risk_index1(bg0, l, h, r);
+    a.cgm[i] = c[1]; a.bg[i] = bg0; a.reward[i] = T(0); a.done[i] = 0;
+    if (a.lbgi) a.lbgi[i] = l;
+    if (a.hbgi) a.hbgi[i] = h;
+    if (a.risk) a.risk[i] = r;
+    if (a.meal) a.meal[i] = T(0);
+    if (a.insulin) a.insulin[i] = T(0);
+}
+
+__global__ void philox_normals_kernel(uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,
+                                      int draw0, int n_draws, double* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t gid = (uint64_t)(env_offset + i);
+    for (int r = 0; r < n_draws; ++r) {
+        const int d = draw0 + r;
+        uint32_t pair; int el;
+        if (d < 0) { const int q = d + 3; pair = 1u + (uint32_t)(q / 2); el = q & 1; }     // random_init_bg normals
+        else if (d == 0) { pair = 0u; el = 0; }
+        else { const int k = (d - 1) % 10, b = (d - 1) / 10; pair = 3u + 5u * (uint32_t)b + (uint32_t)(k / 2); el = k & 1; }
+        const double2 v = philox_pair(seed, gid, episode, pair);
+        out[(int64_t)r * n + i] = el ? v.y : v.x;
+    }
+}
+
+} // namespace t1d
+
+// =============================================================================================
+// host side
+// =============================================================================================
+using namespace t1d;
+
+struct t1d_ctx {
+    int device = -1;
+    int np = 0, S = 0;
+    double sensor[T1D_SENSOR_NCOLS];
+    double pump[T1D_PUMP_NCOLS];
+    double* d_par64 = nullptr; float* d_par32 = nullptr;
+    double* d_x0 = nullptr;
+    double* d_W64 = nullptr; float* d_W32 = nullptr;
+    int* d_status = nullptr;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define T1D_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(T1D_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+extern "C" int t1d_abi_version(void) { return T1D_ABI_VERSION; }
+extern "C" const char* t1d_last_error(void) { return g_err.c_str(); }
+
+extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients, int n_cols,
+                              const double* sensor_row, const double* pump_row, const double* W, int w_rows,
+                              t1d_ctx** out)
+{
+    try {
+        if (!out) return fail(T1D_E_INVALID, "t1d_ctx_create: out is NULL");
+        *out = nullptr;
+        if (!ptab || !sensor_row || !pump_row || !W) return fail(T1D_E_INVALID, "t1d_ctx_create: NULL table");
+        if (n_cols != T1D_P_NCOLS) return fail(T1D_E_INVALID, "t1d_ctx_create: n_cols must be T1D_P_NCOLS (45)");
+        if (n_patients < 1 || n_patients > kMaxPatients)
+            return fail(T1D_E_INVALID, "t1d_ctx_create: n_patients must be in [1, 64]");
+        const double st = sensor_row[5];
+        if (!(st >= 1.0) || st != std::floor(st) || st > 1440.0)
+            return fail(T1D_E_INVALID, "t1d_ctx_create: sensor sample_time must be a whole number of minutes >= 1");
+        if (w_rows < 1) return fail(T1D_E_INVALID, "t1d_ctx_create: w_rows must be >= 1");
+        for (int k = 2; k < 6; k += 3)
+            if (!(pump_row[k] > 0.0)) return fail(T1D_E_INVALID, "t1d_ctx_create: pump increments must be > 0");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+            return fail(T1D_E_NODEVICE, "t1d_ctx_create: no HIP device visible");
+        if (hip_device < 0 || hip_device >= ndev) return fail(T1D_E_INVALID, "t1d_ctx_create: bad device index");
+        T1D_HIP(hipSetDevice(hip_device));
+
+        t1d_ctx* c = new (std::nothrow) t1d_ctx();
+        if (!c) return fail(T1D_E_INVALID, "t1d_ctx_create: out of host memory");
+        c->device = hip_device; c->np = n_patients; c->S = w_rows;
+        std::memcpy(c->sensor, sensor_row, sizeof(c->sensor));
+        std::memcpy(c->pump, pump_row, sizeof(c->pump));
+
+        const int np = n_patients;
+        std::vector<double> dp((size_t)DP_COUNT * np), x0((size_t)13 * np);
+        for (int j = 0; j < np; ++j) {
+            const double* r = ptab + (size_t)j * n_cols;
+            auto set = [&](int idx, double v) { dp[(size_t)idx * np + j] = v; };
+            set(DP_KMAX, r[T1D_P_KMAX]); set(DP_KMIN, r[T1D_P_KMIN]); set(DP_KABS, r[T1D_P_KABS]);
+            set(DP_HK, (r[T1D_P_KMAX] - r[T1D_P_KMIN]) / 2.0);
+            set(DP_B, r[T1D_P_B]); set(DP_D, r[T1D_P_D]);
+            set(DP_CAA, 5.0 / 2.0 / (1.0 - r[T1D_P_B])); set(DP_CCC, 5.0 / 2.0 / r[T1D_P_D]);
+            set(DP_RATC, r[T1D_P_F] * r[T1D_P_KABS] / r[T1D_P_BW]);
+            set(DP_KP1, r[T1D_P_KP1]); set(DP_KP2, r[T1D_P_KP2]); set(DP_KP3, r[T1D_P_KP3]);
+            set(DP_FSNC, r[T1D_P_FSNC]); set(DP_KE1, r[T1D_P_KE1]); set(DP_KE2, r[T1D_P_KE2]);
+            set(DP_K1, r[T1D_P_K1]); set(DP_K2, r[T1D_P_K2]); set(DP_VM0, r[T1D_P_VM0]);
+            set(DP_VMX, r[T1D_P_VMX]); set(DP_KM0, r[T1D_P_KM0]);
+            set(DP_M24, r[T1D_P_M2] + r[T1D_P_M4]); set(DP_M1, r[T1D_P_M1]);
+            set(DP_KA1, r[T1D_P_KA1]); set(DP_KA2, r[T1D_P_KA2]); set(DP_VI, r[T1D_P_VI]);
+            set(DP_P2U, r[T1D_P_P2U]); set(DP_IB, r[T1D_P_IB]); set(DP_KI, r[T1D_P_KI]);
+            set(DP_M130, r[T1D_P_M1] + r[T1D_P_M30]); set(DP_M2, r[T1D_P_M2]);
+            set(DP_KA1KD, r[T1D_P_KA1] + r[T1D_P_KD]); set(DP_KD, r[T1D_P_KD]); set(DP_KSC, r[T1D_P_KSC]);
+            set(DP_INSC, 6000.0 / r[T1D_P_BW]); set(DP_VG, r[T1D_P_VG]);
+            for (int k = 0; k < 13; ++k) x0[(size_t)k * np + j] = r[T1D_P_X0 + k];
+        }
+        std::vector<float> dpf(dp.begin(), dp.end());
+        std::vector<float> Wf(W, W + (size_t)w_rows * 11);
+        auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(dst, bytes);
+            if (e != hipSuccess) return e;
+            return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        };
+        hipError_t e = hipSuccess;
+        if (e == hipSuccess) e = up((void**)&c->d_par64, dp.data(), dp.size() * 8);
+        if (e == hipSuccess) e = up((void**)&c->d_par32, dpf.data(), dpf.size() * 4);
+        if (e == hipSuccess) e = up((void**)&c->d_x0, x0.data(), x0.size() * 8);
+        if (e == hipSuccess) e = up((void**)&c->d_W64, W, (size_t)w_rows * 11 * 8);
+        if (e == hipSuccess) e = up((void**)&c->d_W32, Wf.data(), Wf.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_status, sizeof(int));
+        if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(int));
+        if (e != hipSuccess) {
+            std::string m = std::string("t1d_ctx_create: ") + hipGetErrorString(e);
+            t1d_ctx_destroy(c);
+            return fail(T1D_E_HIP, m);
+        }
+        *out = c;
+        return T1D_OK;
+    } catch (const std::exception& ex) {
+        return fail(T1D_E_INVALID, std::string("t1d_ctx_create: ") + ex.what());
+    } catch (...) {
+        return fail(T1D_E_INVALID, "t1d_ctx_create: unknown exception");
+    }
+}
+
+extern "C" int t1d_ctx_destroy(t1d_ctx* c)
+{
+    if (!c) return T1D_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_par64); (void)hipFree(c->d_par32); (void)hipFree(c->d_x0);
+    (void)hipFree(c->d_W64); (void)hipFree(c->d_W32); (void)hipFree(c->d_status);
+    delete c;
+    return T1D_OK;
+}
+
+static int check_batch(const char* who, const t1d_ctx* c, const t1d_batch* b, bool need_action)
+{
+    if (!c) return fail(T1D_E_INVALID, std::string(who) + ": ctx is NULL");
+    if (!b) return fail(T1D_E_INVALID, std::string(who) + ": batch is NULL");
+    if (b->n < 1 || b->n > (int64_t)INT32_MAX * 64)
+        return fail(T1D_E_INVALID, std::string(who) + ": batch.n out of range");
+    if (b->dtype != T1D_F64 && b->dtype != T1D_F32) return fail(T1D_E_INVALID, std::string(who) + ": bad dtype");
+    if (!b->x || !b->planned || !b->last_qsto || !b->last_food || !b->t || !b->meta || !b->last_cgm ||
+        !b->ar_e || !b->pts || !b->prev_cgm)
+        return fail(T1D_E_INVALID, std::string(who) + ": a state pointer is NULL");
+    if (!b->cgm || !b->bg || !b->reward || !b->done)
+        return fail(T1D_E_INVALID, std::string(who) + ": cgm/bg/reward/done outputs are required");
+    if (need_action && !b->basal) return fail(T1D_E_INVALID, std::string(who) + ": basal is NULL");
+    if (b->n_meals < 0 || b->n_meals > 65535) return fail(T1D_E_INVALID, std::string(who) + ": n_meals out of range");
+    if (b->n_meals > 0 && (!b->meal_time || !b->meal_amt))
+        return fail(T1D_E_INVALID, std::string(who) + ": n_meals > 0 but meal table pointer is NULL");
+    if (b->n_normals < 0) return fail(T1D_E_INVALID, std::string(who) + ": n_normals < 0");
+    if (b->n_normals > 0 && !b->normals) return fail(T1D_E_INVALID, std::string(who) + ": n_normals > 0 but normals is NULL");
+    return T1D_OK;
+}
+
+template <typename T>
+static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub)
+{
+    KArgs<T> a;
+    a.n = b->n; a.env_offset = b->env_offset; a.seed = b->seed;
+    a.x = (T*)b->x; a.planned = (T*)b->planned; a.last_qsto = (T*)b->last_qsto; a.last_food = (T*)b->last_food;
+    a.t = b->t; a.meta = b->meta; a.episode = b->episode;
+    a.last_cgm = (T*)b->last_cgm; a.ar_e = (T*)b->ar_e; a.pts = (T*)b->pts; a.prev_cgm = (T*)b->prev_cgm;
+    a.basal = (const T*)b->basal; a.bolus = (const T*)b->bolus; a.cho = (const T*)b->cho;
+    a.meal_time = b->meal_time; a.meal_amt = (const T*)b->meal_amt;
+    a.normals = b->n_normals > 0 ? (const T*)b->normals : nullptr;
+    a.x0_override = (const T*)b->x0_override;
+    a.cgm = (T*)b->cgm; a.bg = (T*)b->bg; a.reward = (T*)b->reward; a.done = b->done;
+    a.lbgi = (T*)b->lbgi; a.hbgi = (T*)b->hbgi; a.risk = (T*)b->risk; a.meal = (T*)b->meal; a.insulin = (T*)b->insulin;
+    a.dpar = sizeof(T) == 8 ? (const T*)c->d_par64 : (const T*)c->d_par32;
+    a.x0tab = c->d_x0;
+    a.W = sizeof(T) == 8 ? (const T*)c->d_W64 : (const T*)c->d_W32;
+    a.status = c->d_status;
+    a.sen.pacf = (T)c->sensor[0]; a.sen.gamma = (T)c->sensor[1]; a.sen.lambda = (T)c->sensor[2];
+    a.sen.delta = (T)c->sensor[3]; a.sen.xi = (T)c->sensor[4]; a.sen.st = (int)c->sensor[5];
+    a.sen.vmin = (T)c->sensor[6]; a.sen.vmax = (T)c->sensor[7];
+    a.pump.min_bolus = (T)c->pump[0]; a.pump.max_bolus = (T)c->pump[1]; a.pump.inc_bolus = (T)c->pump[2];
+    a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
+    a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
+    a.minutes = minutes; a.n_sub = n_sub;
+    return a;
+}
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+extern "C" int t1d_reset(t1d_ctx* c, const t1d_batch* b, const uint8_t* mask, int random_init_bg, void* stream)
+{
+    int rc = check_batch("t1d_reset", c, b, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (b->dtype == T1D_F64)
+        hipLaunchKernelGGL(reset_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s, make_args<double>(c, b, 1, 1), mask, random_init_bg);
+    else
+        hipLaunchKernelGGL(reset_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, 1, 1), mask, random_init_bg);
+    T1D_HIP(hipGetLastError());
+    return T1D_OK;
+}
+
+extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, void* stream)
+{
+    int rc = check_batch("t1d_step", c, b, true);
+    if (rc) return rc;
+    if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_step: minutes out of range");
+    if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_step: n_sub out of range");
+    hipStream_t s = (hipStream_t)stream;
+    if (b->dtype == T1D_F64)
+        hipLaunchKernelGGL(step_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s, make_args<double>(c, b, minutes, n_sub));
+    else
+        hipLaunchKernelGGL(step_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
+    T1D_HIP(hipGetLastError());
+    return T1D_OK;
+}
+
+template <typename T>
+static PidArgs<T> make_pid(const t1d_pid* p, int n_steps)
+{
+    PidArgs<T> c;
+    c.P = (T)p->P; c.I = (T)p->I; c.D = (T)p->D; c.target = (T)p->target;
+    c.integ = (T*)p->integ; c.prev = (T*)p->prev; c.sum_risk = (T*)p->sum_risk;
+    c.min_bg = (T*)p->min_bg; c.max_bg = (T*)p->max_bg; c.n_low = p->n_low; c.n_high = p->n_high;
+    c.n_steps = n_steps;
+    return c;
+}
+
+extern "C" int t1d_rollout_pid(t1d_ctx* c, const t1d_batch* b, const t1d_pid* pid, int n_steps, int minutes,
+                               int n_sub, void* stream)
+{
+    int rc = check_batch("t1d_rollout_pid", c, b, false);
+    if (rc) return rc;
+    if (!pid || !pid->integ || !pid->prev) return fail(T1D_E_INVALID, "t1d_rollout_pid: pid state is NULL");
+    if (b->cho) return fail(T1D_E_INVALID, "t1d_rollout_pid: dense cho is not supported, use the meal table");
+    if (n_steps < 1) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_steps < 1");
+    if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_rollout_pid: minutes out of range");
+    if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_sub out of range");
+    hipStream_t s = (hipStream_t)stream;
+    if (b->dtype == T1D_F64)
+        hipLaunchKernelGGL(rollout_pid_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s,
+                           make_args<double>(c, b, minutes, n_sub), make_pid<double>(pid, n_steps));
+    else
+        hipLaunchKernelGGL(rollout_pid_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s,
+                           make_args<float>(c, b, minutes, n_sub), make_pid<float>(pid, n_steps));
+    T1D_HIP(hipGetLastError());
+    return T1D_OK;
+}
+
+extern "C" int t1d_philox_normals(t1d_ctx* c, uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,
+                                  int32_t draw0, int32_t n_draws, double* out, void* stream)
+{
+    if (!c || !out || n < 1 || n_draws < 1 || draw0 < -3) return fail(T1D_E_INVALID, "t1d_philox_normals: bad argument");
+    hipLaunchKernelGGL(philox_normals_kernel, grid_for(n), dim3(kBlock), 0, (hipStream_t)stream, seed, env_offset, n,
+                       episode, draw0, n_draws, out);
+    T1D_HIP(hipGetLastError());
+    return T1D_OK;
+}
+
+extern "C" int t1d_sync(t1d_ctx* c, void* stream, int32_t* status)
+{
+    if (!c) return fail(T1D_E_INVALID, "t1d_sync: ctx is NULL");
+    T1D_HIP(hipStreamSynchronize((hipStream_t)stream));
+    int st = 0;
+    T1D_HIP(hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) T1D_HIP(hipMemset(c->d_status, 0, sizeof(int)));
+    if (status) *status = st;
+    if (st) return fail(T1D_E_STATUS, "t1d_sync: device status bits set: " + std::to_string(st));
+    return T1D_OK;
+}
