@@ -52,7 +52,8 @@ enum {
 /* bits of the device status word returned through t1d_sync */
 enum {
     T1D_ST_NORMALS_EXHAUSTED = 1,   /* host-normals mode ran past n_normals rows; zeros were used */
-    T1D_ST_NONFINITE = 2            /* some env's state became NaN/Inf */
+    T1D_ST_NONFINITE = 2,           /* some env's state became NaN/Inf */
+    T1D_ST_BAD_LAYOUT = 4           /* T1D_BATCH_WAVE_UNIFORM was set but a wave holds two patients; that wave was skipped */
 };
 
 /* columns of one row of the patient table given to t1d_ctx_create (all double):
@@ -76,6 +77,13 @@ enum {
 #define T1D_META_EATING      0x100u
 #define T1D_META_CURSOR(m)   ((m) >> 16)
 
+/* t1d_batch.flags */
+enum {
+    /* every aligned run of 64 consecutive envs simulates ONE patient (same meta patient row):
+     * the kernels then keep that patient's parameters in scalar registers. */
+    T1D_BATCH_WAVE_UNIFORM = 1
+};
+
 typedef struct t1d_ctx t1d_ctx;
 
 typedef struct t1d_batch {
@@ -84,7 +92,7 @@ typedef struct t1d_batch {
     int32_t dtype;            /* T1D_F64 | T1D_F32 */
     int32_t n_meals;          /* rows of the meal table (0 = none) */
     int32_t n_normals;        /* rows of `normals` (0 = draw in-kernel with Philox) */
-    int32_t reserved;
+    int32_t flags;            /* T1D_BATCH_* */
     uint64_t seed;            /* Philox key */
     /* ---- state (read + written by t1d_step; written by t1d_reset) */
     void* x;                  /* [13][n] ODE state */
@@ -140,6 +148,13 @@ int t1d_ctx_create(int hip_device, const double* patient_table, int n_patients, 
                    const double* sensor_row, const double* pump_row, const double* spline_W,
                    int w_rows, t1d_ctx** out);
 int t1d_ctx_destroy(t1d_ctx* ctx);
+
+/* Tuning/diagnostic switches.  "math": 1 (default) = exp-based gastric-emptying term and
+ * Newton-refined reciprocals in the ODE right-hand side; 0 = ocml tanh and IEEE divisions written
+ * exactly as t1dpatient.py:138-140,171,178 writes them (A/B and parity reference).
+ * "scalar_params": 1 (default) = batches flagged T1D_BATCH_WAVE_UNIFORM use the kernels that keep
+ * the patient row in scalar registers; 0 = always read parameters from the LDS table. */
+int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after
  * T1DSimEnv.reset(): cgm = CGM sample #1, prev_cgm = CGM sample #0, bg/lbgi/hbgi/risk of the

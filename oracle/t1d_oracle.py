@@ -296,3 +296,50 @@ def random_scenario_cho(seed, start_minute_of_day, n_minutes):
         if float(tod) in times:
             cho[m] = amounts[times.index(float(tod))]
     return cho
+
+
+# ----------------------------------------------------------------------------- controllers (C1, C2)
+def quest_table():
+    hdr, rows = _read_csv(os.path.join(_PARAMS, "Quest.csv"))
+    return {r[0]: {h: float(v) for h, v in zip(hdr[1:], r[1:])} for r in rows}
+
+
+def bb_policy(name, meal, glucose, sample_time, target=140.0):
+    """BBController._bb_policy (controller/basal_bolus_ctrller.py:34-80) -> (basal, bolus) U/min."""
+    names, tab = patient_table()
+    q = quest_table()[name]
+    row = tab[names.index(name)]
+    basal = row[IDX["u2ss"]] * row[IDX["BW"]] / 6000.0                        # :64
+    if meal > 0:
+        bolus = (meal * sample_time) / q["CR"] + (glucose > 150) * (glucose - target) / q["CF"]   # :69-71
+    else:
+        bolus = 0.0
+    return basal, bolus / sample_time                                         # :79
+
+
+def closed_loop(patient_name, sensor, sensor_seed, scen_seed, n_steps, policy, start_minute_of_day=0,
+                integrator="dopri", n_sub=4):
+    """SimObj.simulate (simulation/sim_engine.py:29-39) for one env on the oracle: reset, then
+    n_steps x (policy(obs, info) -> env.step).  `policy(cgm, info) -> (basal, bolus)`.
+    Returns the show_history() columns (simulation/env.py:169-180) as a dict of arrays (n_steps+1
+    rows for BG/CGM/LBGI/HBGI/Risk, n_steps for CHO/insulin)."""
+    names, _ = patient_table()
+    st = int(sensor_row(sensor)[5])
+    z = np.random.RandomState(sensor_seed).randn(1 + 10 * (2 + (n_steps * st) // 150))
+    env = OracleEnv([names.index(patient_name)], sensor=sensor, normals=z[:, None], integrator=integrator, n_sub=n_sub)
+    cho = random_scenario_cho(scen_seed, start_minute_of_day, n_steps * st)
+    r = env.reset()
+    hist = {"BG": [r["bg"][0]], "CGM": [r["cgm_hist0"][0]], "LBGI": [r["lbgi"][0]], "HBGI": [r["hbgi"][0]],
+            "Risk": [r["risk"][0]], "CHO": [], "insulin": []}
+    obs, info = r["cgm"][0], {"meal": 0.0, "sample_time": float(st), "patient_name": patient_name}
+    actions = []
+    for k in range(n_steps):
+        basal, bolus = policy(obs, info)
+        actions.append((basal, bolus))
+        o = env.step(basal, bolus, cho[k * st:(k + 1) * st, None])
+        obs = o["cgm"][0]
+        info["meal"] = o["meal"][0]
+        for key, src in (("BG", "bg"), ("CGM", "cgm"), ("LBGI", "lbgi"), ("HBGI", "hbgi"), ("Risk", "risk"),
+                         ("CHO", "meal"), ("insulin", "insulin")):
+            hist[key].append(o[src][0])
+    return {k: np.array(v) for k, v in hist.items()}, np.array(actions)

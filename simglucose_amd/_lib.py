@@ -6,17 +6,18 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libt1d_hip.so")
+LIB_PATH = os.environ.get("T1D_LIB_PATH") or os.path.join(_PKG, "libt1d_hip.so")   # override: A/B builds only
 SOURCES = [os.path.join(_PKG, "csrc", "t1d_abi.hip"), os.path.join(_PKG, "csrc", "t1d_device.hpp"),
            os.path.join(_ROOT, "include", "t1d.h")]
 
 T1D_F64, T1D_F32 = 0, 1
-T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE = 1, 2
+T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE, T1D_ST_BAD_LAYOUT = 1, 2, 4
+T1D_BATCH_WAVE_UNIFORM = 1
 P_NCOLS = 45
 MEAL_UNUSED = 0x7FFFFFFF
 META_EATING = 0x100
 
-EXPORTS = ("t1d_abi_version", "t1d_last_error", "t1d_ctx_create", "t1d_ctx_destroy", "t1d_reset",
+EXPORTS = ("t1d_abi_version", "t1d_last_error", "t1d_ctx_create", "t1d_ctx_set_option", "t1d_ctx_destroy", "t1d_reset",
            "t1d_step", "t1d_rollout_pid", "t1d_philox_normals", "t1d_sync")
 
 
@@ -28,7 +29,7 @@ class Batch(C.Structure):
     """struct t1d_batch (include/t1d.h)"""
     _fields_ = [
         ("n", C.c_int64), ("env_offset", C.c_int64), ("dtype", C.c_int32), ("n_meals", C.c_int32),
-        ("n_normals", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
+        ("n_normals", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64),
         ("x", C.c_void_p), ("planned", C.c_void_p), ("last_qsto", C.c_void_p), ("last_food", C.c_void_p),
         ("t", C.c_void_p), ("meta", C.c_void_p), ("episode", C.c_void_p),
         ("last_cgm", C.c_void_p), ("ar_e", C.c_void_p), ("pts", C.c_void_p), ("prev_cgm", C.c_void_p),
@@ -83,6 +84,7 @@ def lib():
     L.t1d_last_error.restype = C.c_char_p
     L.t1d_ctx_create.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.POINTER(vp)]
     L.t1d_ctx_destroy.argtypes = [vp]
+    L.t1d_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
     L.t1d_reset.argtypes = [vp, C.POINTER(Batch), vp, C.c_int, vp]
     L.t1d_step.argtypes = [vp, C.POINTER(Batch), C.c_int, C.c_int, vp]
     L.t1d_rollout_pid.argtypes = [vp, C.POINTER(Batch), C.POINTER(Pid), C.c_int, C.c_int, C.c_int, vp]

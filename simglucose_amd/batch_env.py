@@ -96,6 +96,11 @@ class BatchedT1DSimEnv:
             tns = getattr(self, k)
             setattr(b, k, tns.data_ptr() if tns is not None else None)
         b.n_meals = 0; b.n_normals = 0
+        # patient-homogeneous waves (aligned runs of 64 envs) let the kernels hold parameters in SGPRs
+        pad = (-self.n) % 64
+        runs = np.concatenate([pid, np.full(pad, pid[-1])]).reshape(-1, 64)
+        self.wave_uniform = bool((runs == runs[:, :1]).all())
+        b.flags = _lib.T1D_BATCH_WAVE_UNIFORM if self.wave_uniform else 0
         if noise not in ("philox", "host"):
             raise ValueError("noise must be 'philox' or 'host'")
         self.noise = noise
@@ -133,6 +138,10 @@ class BatchedT1DSimEnv:
             raise ValueError("meal tables must both have shape [n_meals, n]")
         self.meal_time, self.meal_amt = mt, ma
         self._b.meal_time, self._b.meal_amt, self._b.n_meals = mt.data_ptr(), ma.data_ptr(), mt.shape[0]
+
+    def set_option(self, name, value):
+        """t1d_ctx_set_option: e.g. ("math", 0) selects the ocml-tanh / IEEE-division RHS variant."""
+        _lib.check(self._L.t1d_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

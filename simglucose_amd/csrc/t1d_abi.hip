@@ -9,6 +9,10 @@
 #include "../../include/t1d.h"
 #include "t1d_device.hpp"
 
+#ifndef T1D_WAVES
+#define T1D_WAVES 2
+#endif
+
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -27,7 +31,7 @@ template <typename T> struct KArgs {
     const T* basal; const T* bolus; const T* cho; const int32_t* meal_time; const T* meal_amt;
     const T* normals; const T* x0_override;
     T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin;
-    const T* dpar;          // [DP_COUNT][np] derived patient constants
+    const T* dpar;          // [DP_COUNT][kMaxPatients] derived patient constants
     const double* x0tab;    // [13][np]
     const T* W;             // [S][11]
     int* status;
@@ -41,6 +45,25 @@ template <typename T> struct PidArgs {
     int n_steps;
 };
 
+// Row k of a [K][n] array as a wave-uniform base pointer: the lane index i then rides in ONE 32-bit
+// VGPR offset shared by every array (global_load ... v_off, s[base]) instead of a 64-bit address
+// pair per array kept alive from the first load to the last store.
+// The empty asm pins the row base in an SGPR pair and hides its provenance, so loads and stores take the
+// `global_* v_off, s[base:base+1]` form and no per-row 64-bit VGPR address survives from load to store.
+template <typename U> __device__ __forceinline__ U* row(U* base, int64_t n, int k)
+{
+    U* p = base + (int64_t)k * n;
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// row whose index may differ between lanes (meal cursor, noise block): ordinary per-lane address
+template <typename U> __device__ __forceinline__ U* rowv(U* base, int64_t n, int k) { return base + (int64_t)k * n; }
+// element i of a uniform-base array through an explicit 32-bit BYTE offset (i < 2^28 by contract)
+template <typename U> __device__ __forceinline__ U& at(U* base, unsigned i)
+{
+    return *(U*)((char*)base + (unsigned)(i * (unsigned)sizeof(U)));
+}
+
 // env state held in registers across the minutes of a launch
 template <typename T> struct Env {
     T x[13];
@@ -53,84 +76,93 @@ template <typename T> struct StepOut { T cgm, bg, meal, ins; };
 template <typename T>
 __device__ __forceinline__ void stage_pars(const KArgs<T>& a, T* lds)
 {
-    const int tot = DP_COUNT * a.np;
+    const int tot = DP_COUNT * kMaxPatients;
     for (int j = threadIdx.x; j < tot; j += blockDim.x) lds[j] = a.dpar[j];
     __syncthreads();
 }
 
 template <typename T>
-__device__ __forceinline__ void load_env(const KArgs<T>& a, int64_t i, uint32_t meta, Env<T>& e)
+__device__ __forceinline__ void load_env(const KArgs<T>& a, unsigned i, uint32_t meta, Env<T>& e)
 {
-    const int64_t n = a.n;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) e.x[k] = a.x[k * n + i];
-    e.planned = a.planned[i]; e.lq = a.last_qsto[i]; e.lf = a.last_food[i];
-    e.last_cgm = a.last_cgm[i]; e.ar_e = a.ar_e[i]; e.prev_cgm = a.prev_cgm[i];
-    e.t = a.t[i];
+    for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
+    e.planned = at(a.planned, i); e.lq = at(a.last_qsto, i); e.lf = at(a.last_food, i);
+    e.last_cgm = at(a.last_cgm, i); e.ar_e = at(a.ar_e, i); e.prev_cgm = at(a.prev_cgm, i);
+    e.t = at(a.t, i);
     e.eating = (meta & T1D_META_EATING) != 0;
     e.cursor = (int)T1D_META_CURSOR(meta);
 }
 
 template <typename T>
-__device__ __forceinline__ void store_env(const KArgs<T>& a, int64_t i, uint32_t pid, const Env<T>& e)
+__device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_t pid, const Env<T>& e)
 {
-    const int64_t n = a.n;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) a.x[k * n + i] = e.x[k];
-    a.planned[i] = e.planned; a.last_qsto[i] = e.lq; a.last_food[i] = e.lf;
-    a.last_cgm[i] = e.last_cgm; a.ar_e[i] = e.ar_e; a.prev_cgm[i] = e.prev_cgm;
-    a.t[i] = e.t;
-    a.meta[i] = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+    for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
+    at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
+    at(a.last_cgm, i) = e.last_cgm; at(a.ar_e, i) = e.ar_e; at(a.prev_cgm, i) = e.prev_cgm;
+    at(a.t, i) = e.t;
+    at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
 }
 
-// next(CGMNoise) for sample index s (noise_gen.py:61-69; refill :30-56; AR(1) source :84-97).
+// Refill of the CGM noise deque (noise_gen.py:30-56): ten new AR(1) -> Johnson-SU points at 15-min
+// spacing (:84-97) behind the carried-over last point.  Runs once per 150 simulated minutes per env,
+// so it is kept out of line: its registers (ocml sinh, Philox) are paid for on this path only.
+// Returns sample 0 of the new block, W[0] . points.
 template <typename T>
-__device__ __forceinline__ T noise_sample(const KArgs<T>& a, int64_t i, int s, T& ar_e)
+__device__ __noinline__ T noise_refill(T* __restrict__ pts, const T* __restrict__ normals, const T* __restrict__ w,
+                                       const uint32_t* __restrict__ episode, int* status, int64_t n, unsigned i,
+                                       int64_t env_offset, uint64_t seed, int n_normals, int b, SensorC<T> sen, T* ar_e)
+{
+    const T p0 = at(rowv(pts, n, b > 0 ? 10 : 0), i);          // carried-over last point (:33,36)
+    at(pts, i) = p0;
+    T acc = w[0] * p0;
+    T e = *ar_e;
+    const uint32_t ep = (!normals && episode) ? at(episode, i) : 0u;
+#pragma unroll 1
+    for (int q = 0; q < 5; ++q) {
+        T z0, z1;
+        if (normals) {
+            const int d = 1 + 10 * b + 2 * q;
+            if (d + 1 < n_normals) { z0 = at(rowv(normals, n, d), i); z1 = at(rowv(normals, n, d + 1), i); }
+            else { z0 = z1 = T(0); atomicOr(status, T1D_ST_NORMALS_EXHAUSTED); }
+        } else {
+            const double2 r = philox_pair(seed, (uint64_t)(env_offset + i), ep, 3u + 5u * (uint32_t)b + (uint32_t)q);
+            z0 = (T)r.x; z1 = (T)r.y;
+        }
+        e = sen.pacf * (e + z0);                         // :88
+        T v = johnson_su<true>(sen, e);
+        at(rowv(pts, n, 2 * q + 1), i) = v; acc += w[2 * q + 1] * v;
+        e = sen.pacf * (e + z1);
+        v = johnson_su<true>(sen, e);
+        at(rowv(pts, n, 2 * q + 2), i) = v; acc += w[2 * q + 2] * v;
+    }
+    *ar_e = e;
+    return acc;
+}
+
+// next(CGMNoise) for sample index s (noise_gen.py:61-69).
+template <typename T>
+__device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, T& ar_e)
 {
     const int64_t n = a.n;
     const int j = s % a.S, b = s / a.S;
     const T* w = a.W + j * 11;
     T acc;
     if (j == 0) {                       // deque empty: build the next 150-minute block
-        T p[11];
-        p[0] = a.pts[(b > 0 ? 10 : 0) * n + i];     // carried-over last point (:33,36)
-        T z[10];
-        if (a.normals) {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                const int d = 1 + 10 * b + k;
-                if (d < a.n_normals) z[k] = a.normals[(int64_t)d * n + i];
-                else { z[k] = T(0); atomicOr(a.status, T1D_ST_NORMALS_EXHAUSTED); }
-            }
-        } else {
-            const uint32_t ep = a.episode ? a.episode[i] : 0u;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const double2 r = philox_pair(a.seed, (uint64_t)(a.env_offset + i), ep, 3u + 5u * (uint32_t)b + q);
-                z[2 * q] = (T)r.x; z[2 * q + 1] = (T)r.y;
-            }
-        }
         T e = ar_e;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            e = a.sen.pacf * (e + z[k]);                // :88
-            p[k + 1] = johnson_su(a.sen, e);
-        }
+        acc = noise_refill<T>(a.pts, a.normals, w, a.episode, a.status, n, i, a.env_offset, a.seed, a.n_normals, b, a.sen, &e);
         ar_e = e;
-        acc = T(0);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { a.pts[k * n + i] = p[k]; acc += w[k] * p[k]; }
     } else {
         acc = T(0);
 #pragma unroll
-        for (int k = 0; k < 11; ++k) acc += w[k] * a.pts[k * n + i];
+        for (int k = 0; k < 11; ++k) acc += w[k] * at(row(a.pts, n, k), i);
     }
     return acc;
 }
 
 // CGMSensor.measure at patient time e.t (cgm.py:26-36); sample index = 1 + t/st after reset used #0,#1.
 template <typename T>
-__device__ __forceinline__ T measure(const KArgs<T>& a, int64_t i, Env<T>& e, T gsub)
+__device__ __forceinline__ T measure(const KArgs<T>& a, unsigned i, Env<T>& e, T gsub)
 {
     if (e.t % a.sen.st == 0) {
         T cgm = gsub + noise_sample(a, i, 1 + e.t / a.sen.st, e.ar_e);
@@ -143,14 +175,14 @@ __device__ __forceinline__ T measure(const KArgs<T>& a, int64_t i, Env<T>& e, T 
 
 // scenario.get_action(time) from the per-env meal table (scenario.py:33-42 / scenario_gen.py:23-31)
 template <typename T>
-__device__ __forceinline__ T meal_lookup(const KArgs<T>& a, int64_t i, Env<T>& e)
+__device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& e)
 {
     T meal = T(0);
     if (e.cursor < a.n_meals) {
-        int mt = a.meal_time[(int64_t)e.cursor * a.n + i];
-        while (mt < e.t && ++e.cursor < a.n_meals) mt = a.meal_time[(int64_t)e.cursor * a.n + i];
+        int mt = at(rowv(a.meal_time, a.n, e.cursor), i);
+        while (mt < e.t && ++e.cursor < a.n_meals) mt = at(rowv(a.meal_time, a.n, e.cursor), i);
         if (e.cursor < a.n_meals && mt == e.t) {
-            meal = a.meal_amt[(int64_t)e.cursor * a.n + i];
+            meal = at(rowv(a.meal_amt, a.n, e.cursor), i);
             ++e.cursor;
         }
     }
@@ -158,82 +190,100 @@ __device__ __forceinline__ T meal_lookup(const KArgs<T>& a, int64_t i, Env<T>& e
 }
 
 // T1DSimEnv.step body (env.py:66-84): `minutes` mini_steps with one action.
-template <typename T>
-__device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, const Pars<T>& p, int64_t i, Env<T>& e,
-                                                T basal, T bolus)
+template <int MATH, typename T, typename P>
+__device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
+                                                T basal, T bolus, bool has_bolus)
 {
     const T q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
-    const T q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
+    T q_bolus = a.pump.min_bolus > T(0) ? a.pump.min_bolus : T(0);     // = pump.bolus(0)
+    if (has_bolus) q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
     const T insulin = q_basal + q_bolus;
-    const T div = T(a.minutes);
+    const T div = T(a.minutes), inv_div = T(1) / div;
     StepOut<T> o{T(0), T(0), T(0), T(0)};
     for (int m = 0; m < a.minutes; ++m) {
-        const T meal = a.cho ? a.cho[(int64_t)m * a.n + i] : meal_lookup(a, i, e);      // env.py:50
-        const MinuteIn<T> u = eat_minute(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
-        rk4_minute(p, u, e.x, a.n_sub);
+        const T meal = a.cho ? at(row(a.cho, a.n, m), i) : meal_lookup(a, i, e);      // env.py:50
+        const MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+        rk4_minute<MATH>(p, u, e.x, a.n_sub);
         e.t += 1;
-        const T gsub = e.x[12] / p.vg;                   // t1dpatient.py:217-218
+        const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
         const T cgm = measure(a, i, e, gsub);            // env.py:62
-        o.meal += meal / div; o.ins += insulin / div; o.bg += gsub / div; o.cgm += cgm / div;   // env.py:78-81
+        if (MATH == 0) { o.meal += meal / div; o.ins += insulin / div; o.bg += gsub / div; o.cgm += cgm / div; }   // env.py:78-81
+        else { o.meal += meal * inv_div; o.ins += insulin * inv_div; o.bg += gsub * inv_div; o.cgm += cgm * inv_div; }
     }
+    if (MATH != 0 && a.minutes == 1) { o.ins = insulin; }   // x * (1/1) is exact already; keeps -0 out
     return o;
 }
 
-template <typename T>
-__device__ __forceinline__ void write_outputs(const KArgs<T>& a, int64_t i, Env<T>& e, const StepOut<T>& o)
+template <int MATH, typename T>
+__device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env<T>& e, const StepOut<T>& o)
 {
     T l, h, r, rp, rc;
-    risk_index1(e.prev_cgm, l, h, rp);                    // risk_diff, env.py:27-33
-    risk_index1(o.cgm, l, h, rc);
-    a.reward[i] = rp - rc;
+    risk_index1<MATH>(e.prev_cgm, l, h, rp);              // risk_diff, env.py:27-33
+    risk_index1<MATH>(o.cgm, l, h, rc);
+    at(a.reward, i) = rp - rc;
     e.prev_cgm = o.cgm;
-    risk_index1(o.bg, l, h, r);                           // env.py:85
-    a.cgm[i] = o.cgm; a.bg[i] = o.bg;
-    a.done[i] = (o.bg < T(70) || o.bg > T(350)) ? 1 : 0;  // env.py:103
-    if (a.lbgi) a.lbgi[i] = l;
-    if (a.hbgi) a.hbgi[i] = h;
-    if (a.risk) a.risk[i] = r;
-    if (a.meal) a.meal[i] = o.meal;
-    if (a.insulin) a.insulin[i] = o.ins;
+    at(a.cgm, i) = o.cgm; at(a.bg, i) = o.bg;
+    at(a.done, i) = (o.bg < T(70) || o.bg > T(350)) ? 1 : 0;  // env.py:103
+    if (a.lbgi || a.hbgi || a.risk) {
+        risk_index1<MATH>(o.bg, l, h, r);                 // env.py:85
+        if (a.lbgi) at(a.lbgi, i) = l;
+        if (a.hbgi) at(a.hbgi, i) = h;
+        if (a.risk) at(a.risk, i) = r;
+    }
+    if (a.meal) at(a.meal, i) = o.meal;
+    if (a.insulin) at(a.insulin, i) = o.ins;
     if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void step_kernel(const KArgs<T> a)
+// VARIANT 0: reference arithmetic (ocml tanh, IEEE divisions), parameters from LDS
+//         1: fast arithmetic, parameters re-read from LDS per RHS evaluation (any patient layout)
+//         2: fast arithmetic, wave-uniform patient, parameters in SGPRs (T1D_BATCH_WAVE_UNIFORM)
+//         3: fast arithmetic, parameters gathered once per lane into VGPRs (any patient layout)
+template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
+
+template <int VARIANT, typename T>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> a)
 {
-    __shared__ T lds[DP_COUNT * kMaxPatients];
-    stage_pars(a, lds);
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.n) return;
-    const uint32_t meta = a.meta[i];
+    constexpr int MATH = VariantMath<VARIANT>::value;
+    __shared__ T lds[VARIANT >= 2 ? 1 : DP_COUNT * kMaxPatients];
+    if (VARIANT < 2) stage_pars(a, lds);
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
+    if ((int64_t)i >= a.n) return;
+    const uint32_t meta = at(a.meta, i);
     const uint32_t pid = T1D_META_PID(meta);
-    const Pars<T> p = load_pars(lds, a.np, (int)pid);
     Env<T> e;
     load_env(a, i, meta, e);
-    const T basal = a.basal[i];
-    const T bolus = a.bolus ? a.bolus[i] : T(0);
-    const StepOut<T> o = step_body(a, p, i, e, basal, bolus);
-    write_outputs(a, i, e, o);
+    const T basal = at(a.basal, i);
+    const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+    StepOut<T> o;
+    if (VARIANT == 2) {
+        const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
+        if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
+        ParsScalar<T> p;
+        p.load(a.dpar, kMaxPatients, pid0);
+        o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+    } else if (VARIANT == 3) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+    } else {
+        ParsLds<T> p{lds, (int)pid};
+        o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+    }
+    write_outputs<MATH>(a, i, e, o);
     store_env(a, i, pid, e);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void rollout_pid_kernel(const KArgs<T> a, const PidArgs<T> c)
+template <int VARIANT, typename T, typename P>
+__device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>& c, P& p, unsigned i, uint32_t pid, Env<T>& e)
 {
-    __shared__ T lds[DP_COUNT * kMaxPatients];
-    stage_pars(a, lds);
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.n) return;
-    const uint32_t meta = a.meta[i];
-    const uint32_t pid = T1D_META_PID(meta);
-    const Pars<T> p = load_pars(lds, a.np, (int)pid);
-    Env<T> e;
-    load_env(a, i, meta, e);
-    T obs = a.cgm[i];
-    T integ = c.integ[i], prev = c.prev[i];
-    T sum_risk = c.sum_risk ? c.sum_risk[i] : T(0);
-    T min_bg = c.min_bg ? c.min_bg[i] : T(0), max_bg = c.max_bg ? c.max_bg[i] : T(0);
-    int n_low = c.n_low ? c.n_low[i] : 0, n_high = c.n_high ? c.n_high[i] : 0;
+    constexpr int MATH = VariantMath<VARIANT>::value;
+    T obs = at(a.cgm, i);
+    T integ = at(c.integ, i), prev = at(c.prev, i);
+    T sum_risk = c.sum_risk ? at(c.sum_risk, i) : T(0);
+    T min_bg = c.min_bg ? at(c.min_bg, i) : T(0), max_bg = c.max_bg ? at(c.max_bg, i) : T(0);
+    int n_low = c.n_low ? at(c.n_low, i) : 0, n_high = c.n_high ? at(c.n_high, i) : 0;
     const T st = T(a.sen.st);
     StepOut<T> o{obs, T(0), T(0), T(0)};
     T pre_prev_cgm = e.prev_cgm;
@@ -242,44 +292,71 @@ __global__ __launch_bounds__(kBlock) void rollout_pid_kernel(const KArgs<T> a, c
         const T u = c.P * (obs - c.target) + c.I * integ + c.D * (obs - prev) / st;
         prev = obs;
         integ += (obs - c.target) * st;
-        o = step_body(a, p, i, e, u, T(0));
+        o = step_body<MATH>(a, p, i, e, u, T(0), true);
         obs = o.cgm;
         pre_prev_cgm = e.prev_cgm;
         e.prev_cgm = o.cgm;                      // CGM history advances every step
-        T l, h, r;
-        risk_index1(o.bg, l, h, r);
-        sum_risk += r;
+        if (c.sum_risk) { T l, h, r; risk_index1<MATH>(o.bg, l, h, r); sum_risk += r; }
         min_bg = o.bg < min_bg ? o.bg : min_bg;
         max_bg = o.bg > max_bg ? o.bg : max_bg;
         n_low += o.bg < T(70); n_high += o.bg > T(180);
     }
     e.prev_cgm = pre_prev_cgm;                   // write_outputs forms the last step's reward from it
-    write_outputs(a, i, e, o);
+    write_outputs<MATH>(a, i, e, o);
     store_env(a, i, pid, e);
-    c.integ[i] = integ; c.prev[i] = prev;
-    if (c.sum_risk) c.sum_risk[i] = sum_risk;
-    if (c.min_bg) c.min_bg[i] = min_bg;
-    if (c.max_bg) c.max_bg[i] = max_bg;
-    if (c.n_low) c.n_low[i] = n_low;
-    if (c.n_high) c.n_high[i] = n_high;
+    at(c.integ, i) = integ; at(c.prev, i) = prev;
+    if (c.sum_risk) at(c.sum_risk, i) = sum_risk;
+    if (c.min_bg) at(c.min_bg, i) = min_bg;
+    if (c.max_bg) at(c.max_bg, i) = max_bg;
+    if (c.n_low) at(c.n_low, i) = n_low;
+    if (c.n_high) at(c.n_high, i) = n_high;
+}
+
+template <int VARIANT, typename T>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void rollout_pid_kernel(const KArgs<T> a, const PidArgs<T> c)
+{
+    __shared__ T lds[VARIANT >= 2 ? 1 : DP_COUNT * kMaxPatients];
+    if (VARIANT < 2) stage_pars(a, lds);
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
+    if ((int64_t)i >= a.n) return;
+    const uint32_t meta = at(a.meta, i);
+    const uint32_t pid = T1D_META_PID(meta);
+    Env<T> e;
+    load_env(a, i, meta, e);
+    if (VARIANT == 2) {
+        const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
+        if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
+        ParsScalar<T> p;
+        p.load(a.dpar, kMaxPatients, pid0);
+        rollout_body<VARIANT>(a, c, p, i, pid, e);
+    } else if (VARIANT == 3) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        rollout_body<VARIANT>(a, c, p, i, pid, e);
+    } else {
+        ParsLds<T> p{lds, (int)pid};
+        rollout_body<VARIANT>(a, c, p, i, pid, e);
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const uint8_t* mask, int random_init_bg)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.n) return;
-    if (mask && !mask[i]) return;
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
+    if ((int64_t)i >= a.n) return;
+    if (mask && !at(mask, i)) return;
     const int64_t n = a.n;
-    const uint32_t pid = T1D_META_PID(a.meta[i]);
+    const uint32_t pid = T1D_META_PID(at(a.meta, i));
     uint32_t ep = 0;
-    if (a.episode) { ep = a.episode[i] + 1u; a.episode[i] = ep; }
+    if (a.episode) { ep = at(a.episode, i) + 1u; at(a.episode, i) = ep; }
     const uint64_t gid = (uint64_t)(a.env_offset + i);
     Env<T> e;
     // T1DPatient.reset (t1dpatient.py:247-281)
 #pragma unroll
     for (int k = 0; k < 13; ++k)
-        e.x[k] = a.x0_override ? a.x0_override[k * n + i] : (T)a.x0tab[k * a.np + pid];
+        e.x[k] = a.x0_override ? at(row(a.x0_override, n, k), i) : (T)a.x0tab[k * a.np + pid];
     if (random_init_bg && !a.x0_override) {          // :256-270, statistical counterpart
         const double2 r1 = philox_pair(a.seed, gid, ep, 1u), r2 = philox_pair(a.seed, gid, ep, 2u);
         e.x[3] += t_sqrt(T(0.1) * e.x[3]) * (T)r1.x;
@@ -290,14 +367,14 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
     // CGMSensor.reset -> CGMNoise(): first AR value and first 15-min point (noise_gen.py:24,86)
     T z0;
     if (a.normals) {
-        if (a.n_normals > 0) z0 = a.normals[i]; else { z0 = T(0); atomicOr(a.status, T1D_ST_NORMALS_EXHAUSTED); }
+        if (a.n_normals > 0) z0 = at(a.normals, i); else { z0 = T(0); atomicOr(a.status, T1D_ST_NORMALS_EXHAUSTED); }
     } else {
         z0 = (T)philox_pair(a.seed, gid, ep, 0u).x;
     }
     e.ar_e = z0;
-    a.pts[i] = johnson_su(a.sen, z0);
+    at(a.pts, i) = johnson_su<true>(a.sen, z0);
     e.last_cgm = T(0);
-    const T vg = a.dpar[DP_VG * a.np + pid];
+    const T vg = a.dpar[DP_VG * kMaxPatients + pid];
     const T bg0 = e.x[12] / vg;
     T c[2];
     for (int s = 0; s < 2; ++s) {                    // env.py:126 (history[0]) and env.py:142 (observation)
@@ -310,13 +387,13 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
     e.prev_cgm = c[0];
     store_env(a, i, pid, e);
     T l, h, r;
-    risk_index1(bg0, l, h, r);
-    a.cgm[i] = c[1]; a.bg[i] = bg0; a.reward[i] = T(0); a.done[i] = 0;
-    if (a.lbgi) a.lbgi[i] = l;
-    if (a.hbgi) a.hbgi[i] = h;
-    if (a.risk) a.risk[i] = r;
-    if (a.meal) a.meal[i] = T(0);
-    if (a.insulin) a.insulin[i] = T(0);
+    risk_index1<0>(bg0, l, h, r);
+    at(a.cgm, i) = c[1]; at(a.bg, i) = bg0; at(a.reward, i) = T(0); at(a.done, i) = 0;
+    if (a.lbgi) at(a.lbgi, i) = l;
+    if (a.hbgi) at(a.hbgi, i) = h;
+    if (a.risk) at(a.risk, i) = r;
+    if (a.meal) at(a.meal, i) = T(0);
+    if (a.insulin) at(a.insulin, i) = T(0);
 }
 
 __global__ void philox_normals_kernel(uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,
@@ -352,6 +429,9 @@ struct t1d_ctx {
     double* d_x0 = nullptr;
     double* d_W64 = nullptr; float* d_W32 = nullptr;
     int* d_status = nullptr;
+    int math = 1;            // RHS arithmetic variant (t1d_ctx_set_option "math")
+    int scalar_params = 1;   // allow the SGPR-parameter kernels for wave-uniform batches
+    int params_mode = 0;     // 0 = LDS re-read per RHS evaluation, 1 = gathered once into VGPRs
 };
 
 static thread_local std::string g_err;
@@ -396,10 +476,10 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
         std::memcpy(c->pump, pump_row, sizeof(c->pump));
 
         const int np = n_patients;
-        std::vector<double> dp((size_t)DP_COUNT * np), x0((size_t)13 * np);
+        std::vector<double> dp((size_t)DP_COUNT * kMaxPatients, 0.0), x0((size_t)13 * np);
         for (int j = 0; j < np; ++j) {
             const double* r = ptab + (size_t)j * n_cols;
-            auto set = [&](int idx, double v) { dp[(size_t)idx * np + j] = v; };
+            auto set = [&](int idx, double v) { dp[(size_t)idx * kMaxPatients + j] = v; };
             set(DP_KMAX, r[T1D_P_KMAX]); set(DP_KMIN, r[T1D_P_KMIN]); set(DP_KABS, r[T1D_P_KABS]);
             set(DP_HK, (r[T1D_P_KMAX] - r[T1D_P_KMIN]) / 2.0);
             set(DP_B, r[T1D_P_B]); set(DP_D, r[T1D_P_D]);
@@ -414,7 +494,8 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
             set(DP_P2U, r[T1D_P_P2U]); set(DP_IB, r[T1D_P_IB]); set(DP_KI, r[T1D_P_KI]);
             set(DP_M130, r[T1D_P_M1] + r[T1D_P_M30]); set(DP_M2, r[T1D_P_M2]);
             set(DP_KA1KD, r[T1D_P_KA1] + r[T1D_P_KD]); set(DP_KD, r[T1D_P_KD]); set(DP_KSC, r[T1D_P_KSC]);
-            set(DP_INSC, 6000.0 / r[T1D_P_BW]); set(DP_VG, r[T1D_P_VG]);
+            set(DP_INSC, 6000.0 / r[T1D_P_BW]); set(DP_VG, r[T1D_P_VG]); set(DP_IVI, 1.0 / r[T1D_P_VI]); set(DP_IVG, 1.0 / r[T1D_P_VG]);
+            set(DP_DK, r[T1D_P_KMAX] - r[T1D_P_KMIN]);
             for (int k = 0; k < 13; ++k) x0[(size_t)k * np + j] = r[T1D_P_X0 + k];
         }
         std::vector<float> dpf(dp.begin(), dp.end());
@@ -446,6 +527,27 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
     }
 }
 
+extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
+{
+    if (!c || !name) return fail(T1D_E_INVALID, "t1d_ctx_set_option: NULL argument");
+    if (std::strcmp(name, "math") == 0) {
+        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: math must be 0 or 1");
+        c->math = (int)value;
+        return T1D_OK;
+    }
+    if (std::strcmp(name, "params_mode") == 0) {
+        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be 0 or 1");
+        c->params_mode = (int)value;
+        return T1D_OK;
+    }
+    if (std::strcmp(name, "scalar_params") == 0) {
+        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: scalar_params must be 0 or 1");
+        c->scalar_params = (int)value;
+        return T1D_OK;
+    }
+    return fail(T1D_E_INVALID, std::string("t1d_ctx_set_option: unknown option ") + name);
+}
+
 extern "C" int t1d_ctx_destroy(t1d_ctx* c)
 {
     if (!c) return T1D_OK;
@@ -460,7 +562,7 @@ static int check_batch(const char* who, const t1d_ctx* c, const t1d_batch* b, bo
 {
     if (!c) return fail(T1D_E_INVALID, std::string(who) + ": ctx is NULL");
     if (!b) return fail(T1D_E_INVALID, std::string(who) + ": batch is NULL");
-    if (b->n < 1 || b->n > (int64_t)INT32_MAX * 64)
+    if (b->n < 1 || b->n > (int64_t)1 << 28)
         return fail(T1D_E_INVALID, std::string(who) + ": batch.n out of range");
     if (b->dtype != T1D_F64 && b->dtype != T1D_F32) return fail(T1D_E_INVALID, std::string(who) + ": bad dtype");
     if (!b->x || !b->planned || !b->last_qsto || !b->last_food || !b->t || !b->meta || !b->last_cgm ||
@@ -527,10 +629,14 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_step: minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_step: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    if (b->dtype == T1D_F64)
-        hipLaunchKernelGGL(step_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s, make_args<double>(c, b, minutes, n_sub));
-    else
-        hipLaunchKernelGGL(step_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
+    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (c->params_mode ? 3 : 1));
+#define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
+    if (b->dtype == T1D_F64) {
+        if (variant == 0) T1D_LAUNCH_STEP(0, double); else if (variant == 1) T1D_LAUNCH_STEP(1, double); else if (variant == 2) T1D_LAUNCH_STEP(2, double); else T1D_LAUNCH_STEP(3, double);
+    } else {
+        if (variant == 0) T1D_LAUNCH_STEP(0, float); else if (variant == 1) T1D_LAUNCH_STEP(1, float); else if (variant == 2) T1D_LAUNCH_STEP(2, float); else T1D_LAUNCH_STEP(3, float);
+    }
+#undef T1D_LAUNCH_STEP
     T1D_HIP(hipGetLastError());
     return T1D_OK;
 }
@@ -557,12 +663,15 @@ extern "C" int t1d_rollout_pid(t1d_ctx* c, const t1d_batch* b, const t1d_pid* pi
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_rollout_pid: minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    if (b->dtype == T1D_F64)
-        hipLaunchKernelGGL(rollout_pid_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s,
-                           make_args<double>(c, b, minutes, n_sub), make_pid<double>(pid, n_steps));
-    else
-        hipLaunchKernelGGL(rollout_pid_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s,
-                           make_args<float>(c, b, minutes, n_sub), make_pid<float>(pid, n_steps));
+    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (c->params_mode ? 3 : 1));
+#define T1D_LAUNCH_ROLL(V, TT) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, \
+                                                  make_args<TT>(c, b, minutes, n_sub), make_pid<TT>(pid, n_steps))
+    if (b->dtype == T1D_F64) {
+        if (variant == 0) T1D_LAUNCH_ROLL(0, double); else if (variant == 1) T1D_LAUNCH_ROLL(1, double); else if (variant == 2) T1D_LAUNCH_ROLL(2, double); else T1D_LAUNCH_ROLL(3, double);
+    } else {
+        if (variant == 0) T1D_LAUNCH_ROLL(0, float); else if (variant == 1) T1D_LAUNCH_ROLL(1, float); else if (variant == 2) T1D_LAUNCH_ROLL(2, float); else T1D_LAUNCH_ROLL(3, float);
+    }
+#undef T1D_LAUNCH_ROLL
     T1D_HIP(hipGetLastError());
     return T1D_OK;
 }

@@ -3,8 +3,14 @@
 // One lane = one environment.  The 13-state ODE, the RK4 stages, the pump quantiser, the meal
 // bookkeeping, the CGM noise/clamp/hold and the risk/reward epilogue all run in registers; HBM
 // sees one coalesced read and one coalesced write of the struct-of-arrays state per launch.
-// Per-patient parameters come from a table staged in LDS (param-major, so lanes holding different
-// patients hit different banks and lanes holding the same patient broadcast).
+//
+// Per-patient parameters reach the RHS in one of two ways (template policy):
+//   ParsLds     the table is staged in LDS (param-major: lanes holding different patients hit
+//               different banks, equal patients broadcast) and each RHS evaluation re-reads what it
+//               needs, so no parameter occupies a VGPR across the RK4 loop;
+//   ParsScalar  every lane of the wave simulates the same patient (the host lays envs out in
+//               patient-homogeneous runs of 64): the row is fetched with scalar loads and lives in
+//               SGPRs -- zero VGPRs, zero LDS traffic.
 //
 // Reference behaviour restated here (paths relative to the reference checkout):
 //   rhs()            simglucose/patient/t1dpatient.py:119-208   T1DPatient.model
@@ -19,44 +25,53 @@
 
 namespace t1d {
 
-// ---- derived per-patient constants, one row per patient, stored param-major in LDS ------------
+// ---- derived per-patient constants, one row per patient, stored param-major ---------------------
 enum DevPar : int {
     DP_KMAX = 0, DP_KMIN, DP_KABS, DP_HK /*(kmax-kmin)/2*/, DP_B, DP_D, DP_CAA /*5/2/(1-b)*/,
     DP_CCC /*5/2/d*/, DP_RATC /*f*kabs/BW*/, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2,
     DP_K1, DP_K2, DP_VM0, DP_VMX, DP_KM0, DP_M24 /*m2+m4*/, DP_M1, DP_KA1, DP_KA2, DP_VI, DP_P2U,
     DP_IB, DP_KI, DP_M130 /*m1+m30*/, DP_M2, DP_KA1KD /*ka1+kd*/, DP_KD, DP_KSC, DP_INSC /*6000/BW*/,
-    DP_VG, DP_COUNT
+    DP_VG, DP_IVI /*1/Vi*/, DP_IVG /*1/Vg*/, DP_DK /*kmax-kmin*/, DP_COUNT
 };
-constexpr int kMaxPatients = 64;       // LDS table = DP_COUNT * kMaxPatients * sizeof(T) <= 17.5 KiB
+constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 38 x 64 x 8 B = 19 KiB
 constexpr int kBlock = 256;
 
-template <typename T> struct Pars {
-    T kmax, kmin, kabs, hk, b, d, caa, ccc, ratc, kp1, kp2, kp3, fsnc, ke1, ke2, k1, k2, vm0, vmx,
-      km0, m24, m1, ka1, ka2, vi, p2u, ib, ki, m130, m2, ka1kd, kd, ksc, insc, vg;
+// parameters re-read from LDS at every use; refresh() makes the base opaque so the compiler
+// cannot hoist the reads out of an RHS evaluation and pin them in VGPRs
+template <typename T> struct ParsLds {
+    const T* base;     // the __shared__ table, [DP_COUNT][kMaxPatients]: one ds_read with an immediate offset per use
+    int pid;
+    __device__ __forceinline__ T operator()(int idx) const { return base[idx * kMaxPatients + pid]; }
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(pid)); }
 };
-
-template <typename T>
-__device__ __forceinline__ Pars<T> load_pars(const T* lds, int np, int pid)
-{
-    Pars<T> p;
-#define T1D_LP(field, idx) p.field = lds[(idx) * np + pid]
-    T1D_LP(kmax, DP_KMAX); T1D_LP(kmin, DP_KMIN); T1D_LP(kabs, DP_KABS); T1D_LP(hk, DP_HK);
-    T1D_LP(b, DP_B); T1D_LP(d, DP_D); T1D_LP(caa, DP_CAA); T1D_LP(ccc, DP_CCC); T1D_LP(ratc, DP_RATC);
-    T1D_LP(kp1, DP_KP1); T1D_LP(kp2, DP_KP2); T1D_LP(kp3, DP_KP3); T1D_LP(fsnc, DP_FSNC);
-    T1D_LP(ke1, DP_KE1); T1D_LP(ke2, DP_KE2); T1D_LP(k1, DP_K1); T1D_LP(k2, DP_K2); T1D_LP(vm0, DP_VM0);
-    T1D_LP(vmx, DP_VMX); T1D_LP(km0, DP_KM0); T1D_LP(m24, DP_M24); T1D_LP(m1, DP_M1); T1D_LP(ka1, DP_KA1);
-    T1D_LP(ka2, DP_KA2); T1D_LP(vi, DP_VI); T1D_LP(p2u, DP_P2U); T1D_LP(ib, DP_IB); T1D_LP(ki, DP_KI);
-    T1D_LP(m130, DP_M130); T1D_LP(m2, DP_M2); T1D_LP(ka1kd, DP_KA1KD); T1D_LP(kd, DP_KD);
-    T1D_LP(ksc, DP_KSC); T1D_LP(insc, DP_INSC); T1D_LP(vg, DP_VG);
-#undef T1D_LP
-    return p;
-}
+// parameters gathered once per lane from the (L2-resident) table and held in VGPRs for the launch
+template <typename T> struct ParsReg {
+    T v[DP_COUNT];
+    __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
+    __device__ __forceinline__ void refresh() {}
+    __device__ __forceinline__ void load(const T* __restrict__ tab, int pid)
+    {
+#pragma unroll
+        for (int k = 0; k < DP_COUNT; ++k) v[k] = tab[k * kMaxPatients + pid];
+    }
+};
+// parameters of a wave-uniform patient, fetched once with scalar loads (SGPR resident)
+template <typename T> struct ParsScalar {
+    T v[DP_COUNT];
+    __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
+    __device__ __forceinline__ void refresh() {}
+    __device__ __forceinline__ void load(const T* __restrict__ tab, int np, int pid_uniform)
+    {
+#pragma unroll
+        for (int k = 0; k < DP_COUNT; ++k) v[k] = tab[k * np + pid_uniform];
+    }
+};
 
 // ---- per-minute inputs of the RHS, constant over the RK4 sub-steps (t1dpatient.py:110-111) ----
 template <typename T> struct MinuteIn {
     T d_mg;      // eaten CHO, mg/min                      (:121)
     T ins;       // insulin, pmol/kg/min                   (:122)
-    T aa, cc;    // tanh slopes                            (:136-137)
+    T aa, cc;    // tanh slopes (MATH 0) or twice them (MATH 1)   (:136-137)
     T bD, dD;    // b*Dbar, d*Dbar                         (:139-140)
     bool has_dbar;
 };
@@ -73,60 +88,146 @@ __device__ __forceinline__ double t_rint(double v) { return rint(v); }
 __device__ __forceinline__ float t_rint(float v) { return rintf(v); }
 __device__ __forceinline__ double t_sqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float t_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double t_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float t_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double t_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float t_max(float a, float b) { return fmaxf(a, b); }
 
-// T1DPatient.model (t1dpatient.py:119-208).  k = dx/dt.
-template <typename T>
-__device__ __forceinline__ void rhs(const Pars<T>& p, const MinuteIn<T>& u, const T (&x)[13], T (&k)[13])
+// ---- fast fp64 math ------------------------------------------------------------------------------
+// exp(v) for v in [-745, 350]: n = rint(v log2 e), r = v - n ln2 (two-part), degree-12 Taylor on
+// |r| <= 0.347 (truncation 1.7e-16 relative), scale by 2^n.  19 VALU ops (ocml tanh: ~150).
+__device__ __forceinline__ double exp_core(double v)
 {
+    const double n = rint(v * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, v);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;            // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);        // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);        // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);        // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);        // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);        // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);        // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);        // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);        // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);        // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+__device__ __forceinline__ float exp_core(float v) { return __expf(v); }
+
+// a / b for finite, normal b: v_rcp_f64 seed + two Newton steps + one residual correction
+// (<= 1 ulp; skips the scale/fixup of the IEEE sequence).
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdividef(a, b); }
+
+// log(v) for finite v > 0 (fdlibm-style: v = 2^e m, m in [sqrt(1/2), sqrt 2), s = f/(2+f),
+// degree-7 even polynomial in s^2); ~35 VALU ops, < 1 ulp.
+__device__ __forceinline__ double log_core(double v)
+{
+    int e = __builtin_amdgcn_frexp_exp(v);            // v = m 2^e, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(v);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = fdiv(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return fma(dk, 6.93147180369123816490e-01, f - (hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+}
+__device__ __forceinline__ float log_core(float v) { return __logf(v); }
+
+// ---- T1DPatient.model (t1dpatient.py:119-208): k = dx/dt ------------------------------------------
+// MATH 0: ocml tanh and IEEE divisions, written as the reference writes them.
+// MATH 1: tanh(A) - tanh(C) + 2 = 2 + 2 (Ea - Ec) / ((Ea + 1)(Ec + 1)) with Ea = exp(2A), Ec = exp(2C)
+//         (one exp each, one shared reciprocal; absolute error <= ~4 ulp of the bracket), hence
+//         kgut = kmax + (kmax - kmin) (Ea - Ec) / ((Ea + 1)(Ec + 1)); divisions via fdiv();
+//         u.aa / u.cc hold 2 aa / 2 cc (0 when Dbar <= 0: the exps cancel and kgut = kmax, :142).
+template <int MATH, typename T, typename P>
+__device__ __forceinline__ void rhs(P& p, const MinuteIn<T>& u, const T (&x)[13], T (&k)[13])
+{
+    p.refresh();
     const T qsto = x[0] + x[1];                                               // :126
-    k[0] = -p.kmax * x[0] + u.d_mg;                                            // :133
-    const T kg = p.kmin + p.hk * (t_tanh(u.aa * (qsto - u.bD)) - t_tanh(u.cc * (qsto - u.dD)) + T(2)); // :138-140
-    const T kgut = u.has_dbar ? kg : p.kmax;                                   // :135,142
-    k[1] = p.kmax * x[0] - x[1] * kgut;                                        // :145
-    k[2] = kgut * x[1] - p.kabs * x[2];                                        // :148
-    const T rat = p.ratc * x[2];                                               // :151
-    const T egp = p.kp1 - p.kp2 * x[3] - p.kp3 * x[8];                         // :153
-    const T et = (x[3] > p.ke2) ? p.ke1 * (x[3] - p.ke2) : T(0);               // :158-161
-    const T d3 = (egp > T(0) ? egp : T(0)) + rat - p.fsnc - et - p.k1 * x[3] + p.k2 * x[4];   // :165
+    const T kmax = p(DP_KMAX);
+    k[0] = -kmax * x[0] + u.d_mg;                                              // :133
+    T kgut;
+    if (MATH == 0) {
+        const T kg = p(DP_KMIN) + p(DP_HK) * (t_tanh(u.aa * (qsto - u.bD)) - t_tanh(u.cc * (qsto - u.dD)) + T(2)); // :138-140
+        kgut = u.has_dbar ? kg : kmax;                                         // :135,142
+    } else {
+        const T hi = sizeof(T) == 8 ? T(350) : T(40), lo = sizeof(T) == 8 ? T(-745) : T(-80);
+        const T a2 = t_max(t_min(u.aa * (qsto - u.bD), hi), lo);
+        const T c2 = t_max(t_min(u.cc * (qsto - u.dD), hi), lo);
+        const T ea = exp_core(a2), ec = exp_core(c2);
+        kgut = kmax + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
+    }
+    k[1] = kmax * x[0] - x[1] * kgut;                                          // :145
+    k[2] = kgut * x[1] - p(DP_KABS) * x[2];                                    // :148
+    const T rat = p(DP_RATC) * x[2];                                           // :151
+    const T egp = p(DP_KP1) - p(DP_KP2) * x[3] - p(DP_KP3) * x[8];             // :153
+    const T ke2 = p(DP_KE2);
+    const T et = MATH == 0 ? ((x[3] > ke2) ? p(DP_KE1) * (x[3] - ke2) : T(0))  // :158-161
+                           : p(DP_KE1) * t_max(x[3] - ke2, T(0));
+    const T k1x3 = p(DP_K1) * x[3], k2x4 = p(DP_K2) * x[4];
+    const T d3 = t_max(egp, T(0)) + rat - p(DP_FSNC) - et - k1x3 + k2x4;       // :165
     k[3] = (x[3] >= T(0)) ? d3 : T(0);                                         // :167
-    const T vmt = p.vm0 + p.vmx * x[6];                                        // :169
-    const T uid = vmt * x[4] / (p.km0 + x[4]);                                 // :171
-    const T d4 = -uid + p.k1 * x[3] - p.k2 * x[4];                             // :172
+    const T vmt = p(DP_VM0) + p(DP_VMX) * x[6];                                // :169
+    const T uid = MATH == 0 ? vmt * x[4] / (p(DP_KM0) + x[4]) : fdiv(vmt * x[4], p(DP_KM0) + x[4]);   // :171
+    const T d4 = -uid + k1x3 - k2x4;                                           // :172
     k[4] = (x[4] >= T(0)) ? d4 : T(0);                                         // :173
-    const T d5 = -p.m24 * x[5] + p.m1 * x[9] + p.ka1 * x[10] + p.ka2 * x[11];  // :176
-    const T it = x[5] / p.vi;                                                  // :178
+    const T d5 = -p(DP_M24) * x[5] + p(DP_M1) * x[9] + p(DP_KA1) * x[10] + p(DP_KA2) * x[11];   // :176
+    const T it = MATH == 0 ? x[5] / p(DP_VI) : x[5] * p(DP_IVI);               // :178
     k[5] = (x[5] >= T(0)) ? d5 : T(0);                                         // :179
-    k[6] = -p.p2u * x[6] + p.p2u * (it - p.ib);                                // :182
-    k[7] = -p.ki * (x[7] - it);                                                // :185
-    k[8] = -p.ki * (x[8] - x[7]);                                              // :187
-    const T d9 = -p.m130 * x[9] + p.m2 * x[5];                                 // :190
+    const T p2u = p(DP_P2U);
+    k[6] = -p2u * x[6] + p2u * (it - p(DP_IB));                                // :182
+    const T ki = p(DP_KI);
+    k[7] = -ki * (x[7] - it);                                                  // :185
+    k[8] = -ki * (x[8] - x[7]);                                                // :187
+    const T d9 = -p(DP_M130) * x[9] + p(DP_M2) * x[5];                         // :190
     k[9] = (x[9] >= T(0)) ? d9 : T(0);                                         // :191
-    const T d10 = u.ins - p.ka1kd * x[10];                                     // :194
+    const T d10 = u.ins - p(DP_KA1KD) * x[10];                                 // :194
     k[10] = (x[10] >= T(0)) ? d10 : T(0);                                      // :195
-    const T d11 = p.kd * x[10] - p.ka2 * x[11];                                // :197
+    const T d11 = p(DP_KD) * x[10] - p(DP_KA2) * x[11];                        // :197
     k[11] = (x[11] >= T(0)) ? d11 : T(0);                                      // :198
-    const T d12 = -p.ksc * x[12] + p.ksc * x[3];                               // :201
+    const T ksc = p(DP_KSC);
+    const T d12 = -ksc * x[12] + ksc * x[3];                                   // :201
     k[12] = (x[12] >= T(0)) ? d12 : T(0);                                      // :202
 }
 
 // One minute of classical RK4 in n_sub sub-steps; replaces scipy's DOPRI5 (t1dpatient.py:110-113).
-template <typename T>
-__device__ __forceinline__ void rk4_minute(const Pars<T>& p, const MinuteIn<T>& u, T (&x)[13], int n_sub)
+template <int MATH, typename T, typename P>
+__device__ __forceinline__ void rk4_minute(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub)
 {
     const T h = T(1) / T(n_sub);
     const T hh = T(0.5) * h, h6 = h / T(6);
     T k[13], y[13], acc[13];
     for (int s = 0; s < n_sub; ++s) {
-        rhs(p, u, x, k);
+        rhs<MATH>(p, u, x, k);
 #pragma unroll
         for (int i = 0; i < 13; ++i) { acc[i] = k[i]; y[i] = x[i] + hh * k[i]; }
-        rhs(p, u, y, k);
+        rhs<MATH>(p, u, y, k);
 #pragma unroll
         for (int i = 0; i < 13; ++i) { acc[i] += T(2) * k[i]; y[i] = x[i] + hh * k[i]; }
-        rhs(p, u, y, k);
+        rhs<MATH>(p, u, y, k);
 #pragma unroll
         for (int i = 0; i < 13; ++i) { acc[i] += T(2) * k[i]; y[i] = x[i] + h * k[i]; }
-        rhs(p, u, y, k);
+        rhs<MATH>(p, u, y, k);
 #pragma unroll
         for (int i = 0; i < 13; ++i) x[i] = x[i] + h6 * (acc[i] + k[i]);
     }
@@ -134,8 +235,8 @@ __device__ __forceinline__ void rk4_minute(const Pars<T>& p, const MinuteIn<T>& 
 
 // Meal ingestion bookkeeping of T1DPatient.step (t1dpatient.py:82-107) + _announce_meal (:222-236).
 // Returns the MinuteIn for the integrator.
-template <typename T>
-__device__ __forceinline__ MinuteIn<T> eat_minute(const Pars<T>& p, const T (&x)[13], T meal, T insulin_upm,
+template <int MATH, typename T, typename P>
+__device__ __forceinline__ MinuteIn<T> eat_minute(P& p, const T (&x)[13], T meal, T insulin_upm,
                                                   T& planned, T& last_qsto, T& last_food, bool& was_eating)
 {
     T to_eat = T(0);
@@ -153,18 +254,25 @@ __device__ __forceinline__ MinuteIn<T> eat_minute(const Pars<T>& p, const T (&x)
     was_eating = to_eat > T(0);                             // :102-107
     MinuteIn<T> u;
     u.d_mg = to_eat * T(1000);                              // :121
-    u.ins = insulin_upm * p.insc;                           // :122
+    u.ins = insulin_upm * p(DP_INSC);                       // :122
     const T dbar = last_qsto + last_food * T(1000);         // :130
     u.has_dbar = dbar > T(0);
     const T dsafe = u.has_dbar ? dbar : T(1);
-    u.aa = p.caa / dsafe;                                   // :136
-    u.cc = p.ccc / dsafe;                                   // :137
-    u.bD = p.b * dsafe;
-    u.dD = p.d * dsafe;
+    if (MATH == 0) {
+        u.aa = u.has_dbar ? p(DP_CAA) / dsafe : T(0);       // :136
+        u.cc = u.has_dbar ? p(DP_CCC) / dsafe : T(0);       // :137
+    } else {
+        const T inv2 = u.has_dbar ? T(2) / dsafe : T(0);
+        u.aa = p(DP_CAA) * inv2;
+        u.cc = p(DP_CCC) * inv2;
+    }
+    u.bD = p(DP_B) * dsafe;
+    u.dD = p(DP_D) * dsafe;
     return u;
 }
 
-// InsulinPump.basal/.bolus (pump.py:23-39); rint = round-half-to-even = np.round.
+// InsulinPump.basal/.bolus (pump.py:23-39); rint = round-half-to-even = np.round.  IEEE divisions
+// on purpose: the quantiser must land on the same increment as the reference at exact ties.
 template <typename T>
 __device__ __forceinline__ T pump_quantise(T amount, T inc, T lo, T hi)
 {
@@ -177,10 +285,27 @@ __device__ __forceinline__ T pump_quantise(T amount, T inc, T lo, T hi)
 }
 
 // risk_index([bg], 1) (risk.py:5-17); NaN -> 0 and Inf -> max as numpy.nan_to_num does.
-template <typename T>
+// MATH 1: log(bg)**1.084 = exp(1.084 log(log bg)) with the fast log/exp above; arguments outside
+// (1, inf) are resolved by case analysis with numpy's semantics.
+template <int MATH, typename T>
 __device__ __forceinline__ void risk_index1(T bg, T& lbgi, T& hbgi, T& ri)
 {
-    const T f = T(1.509) * (t_pow(t_log(bg), T(1.084)) - T(5.381));
+    T f;
+    if (MATH == 0) {
+        f = T(1.509) * (t_pow(t_log(bg), T(1.084)) - T(5.381));
+    } else {
+        const T inf = T(__builtin_huge_val());
+        if (bg > T(1) && bg < inf) {           // log(bg) in (0, inf)
+            const T u = log_core(bg);
+            const T pw = exp_core(T(1.084) * log_core(u));
+            f = T(1.509) * (pw - T(5.381));
+        } else {
+            // numpy: log(1)**p = 0; log(0) = -inf and (-inf)**p = +inf; log(inf)**p = inf; log of a
+            // negative or of a value in (0,1) raised to a non-integer power, and NaN, give NaN
+            const T nan = T(__builtin_nan(""));
+            f = bg == T(1) ? T(1.509) * (T(0) - T(5.381)) : ((bg == T(0) || bg == inf) ? inf : nan);
+        }
+    }
     T l = T(0), h = T(0);
     if (f < T(0)) l = T(10) * f * f;
     if (f > T(0)) h = T(10) * f * f;
@@ -193,10 +318,16 @@ __device__ __forceinline__ void risk_index1(T bg, T& lbgi, T& hbgi, T& ri)
 template <typename T> struct SensorC { T pacf, gamma, lambda, delta, xi, vmin, vmax; int st; };
 template <typename T> struct PumpC { T min_bolus, max_bolus, inc_bolus, min_basal, max_basal, inc_basal; };
 
-template <typename T>
+// johnson_transform_SU (noise_gen.py:11-12).  FAST: sinh(v) = (E - 1/E)/2 with E = exp_core(v); the
+// cancellation near v = 0 costs relative, not absolute, accuracy (|error| <= ~2e-16 lambda mg/dL).
+template <bool FAST, typename T>
 __device__ __forceinline__ T johnson_su(const SensorC<T>& s, T e)
 {
-    return s.xi + s.lambda * t_sinh((e - s.gamma) / s.delta);
+    const T v = (e - s.gamma) / s.delta;
+    if (!FAST) return s.xi + s.lambda * t_sinh(v);
+    const T lim = sizeof(T) == 8 ? T(350) : T(40);
+    const T E = exp_core(t_max(t_min(v, lim), -lim));
+    return s.xi + s.lambda * (T(0.5) * (E - fdiv(T(1), E)));
 }
 
 // ---- Philox stream layout ---------------------------------------------------------------------

@@ -1,0 +1,82 @@
+"""CPU suite, part 2: libt1d_hip.so loads without a GPU and exports every function include/t1d.h
+declares; argument validation that needs no device; struct layout of the ctypes mirror."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "t1d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(t1d_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from simglucose_amd import _lib
+    L = _lib.lib()
+    names = _declared_functions()
+    assert len(names) >= 10
+    assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.t1d_abi_version() == 1
+
+
+def test_ctx_create_rejects_bad_arguments_without_touching_a_gpu():
+    from simglucose_amd import _lib, params
+    L = _lib.lib()
+    names, tab = params.patient_table()
+    tab = np.ascontiguousarray(tab)
+    dp = C.POINTER(C.c_double)
+    sen = params.sensor_row("Dexcom"); pump = params.pump_row("Insulet")
+    W = np.ascontiguousarray(params.spline_block_operator(3.0))
+    ctx = C.c_void_p()
+
+    def create(n_cols=45, npat=30, sensor=sen, w_rows=W.shape[0]):
+        return L.t1d_ctx_create(0, tab.ctypes.data_as(dp), npat, n_cols, sensor.ctypes.data_as(dp),
+                                pump.ctypes.data_as(dp), W.ctypes.data_as(dp), w_rows, C.byref(ctx))
+    assert create(n_cols=44) == -1 and b"n_cols" in L.t1d_last_error()
+    assert create(npat=0) == -1
+    assert create(npat=65) == -1
+    bad = sen.copy(); bad[5] = 2.5
+    assert create(sensor=bad) == -1 and b"sample_time" in L.t1d_last_error()
+    assert create(w_rows=0) == -1
+    assert L.t1d_step(None, None, 1, 4, None) == -1
+    assert L.t1d_sync(None, None, None) == -1
+    import torch
+    if not torch.cuda.is_available():
+        rc = create()
+        assert rc in (-3, -2), rc                 # no device: T1D_E_NODEVICE (or a HIP error), never success
+        with pytest.raises(_lib.T1DError):
+            from simglucose_amd.batch_env import BatchedT1DSimEnv
+            BatchedT1DSimEnv(patient="adult#001", n_envs=4)     # product path fails loudly, no CPU fallback
+
+
+def test_batch_struct_layout_matches_header():
+    """Field order/offsets of the ctypes mirror follow struct t1d_batch in include/t1d.h."""
+    from simglucose_amd import _lib
+    src = open(os.path.join(ROOT, "include", "t1d.h")).read()
+    body = src[src.index("typedef struct t1d_batch {"):src.index("} t1d_batch;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S).replace("typedef struct t1d_batch {", "")
+    fields = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if not stmt or stmt.startswith("typedef"):
+            continue
+        fields.append(re.findall(r"([A-Za-z_0-9]+)\s*$", stmt)[0])
+    assert fields == [f[0] for f in _lib.Batch._fields_]
+    assert C.sizeof(_lib.Batch) == 8 + 8 + 4 * 4 + 8 + 8 * (len(fields) - 7)
+    body = src[src.index("typedef struct t1d_pid {"):src.index("} t1d_pid;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    pf = []
+    for stmt in body.replace("typedef struct t1d_pid {", "").split(";"):
+        for part in stmt.split(","):
+            m = re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())
+            if m and part.strip():
+                pf.append(m[0])
+    assert pf == [f[0] for f in _lib.Pid._fields_]

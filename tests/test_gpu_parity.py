@@ -15,11 +15,19 @@ TOL_ORACLE = 1e-8
 TOL_SCIPY = 1e-3
 
 
-def _env(**kw):
+VARIANTS = ("ref", "lds", "scalar")
+
+
+def _env(variant="scalar", **kw):
+    """variant: ref = ocml tanh / IEEE division RHS; lds = fast RHS, parameters from LDS;
+    scalar = fast RHS, SGPR parameters when every wave holds one patient (else falls back to lds)."""
     import torch
     from simglucose_amd.batch_env import BatchedT1DSimEnv
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    return BatchedT1DSimEnv(**kw)
+    env = BatchedT1DSimEnv(**kw)
+    env.set_option("math", 0 if variant == "ref" else 1)
+    env.set_option("scalar_params", 1 if variant == "scalar" else 0)
+    return env
 
 
 def _cho_minutes(hours, grams, n):
@@ -31,9 +39,10 @@ def _cho_minutes(hours, grams, n):
     return cho
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("sensor,seed", [("Dexcom", 1), ("Navigator", 2), ("GuardianRT", 3)])
 @pytest.mark.parametrize("pname", ["adult#001", "child#003"])
-def test_env_step_vs_oracle_and_golden(golden, sensor, seed, pname):
+def test_env_step_vs_oracle_and_golden(golden, sensor, seed, pname, variant):
     """G5: reset + hundreds of steps, random basal + occasional boluses, custom meal scenario,
     host-supplied normals (exact numpy RandomState stream)."""
     import torch
@@ -47,7 +56,8 @@ def test_env_step_vs_oracle_and_golden(golden, sensor, seed, pname):
     st = int(O.sensor_row(sensor)[5])
     cho = _cho_minutes(g["scen_hours"], g["scen_grams"], nstep * st)
 
-    env = _env(patient=[pname] * 3, sensor=sensor, noise="host", normals=np.repeat(z[:, None], 3, 1), n_sub=4)
+    env = _env(variant, patient=[pname] * 3, sensor=sensor, noise="host", normals=np.repeat(z[:, None], 3, 1), n_sub=4)
+    assert env.wave_uniform
     orc = O.OracleEnv([names.index(pname)], sensor=sensor, normals=z[:, None], integrator="rk4", n_sub=4)
     obs0 = env.reset().cpu().numpy()
     r0 = orc.reset()
@@ -89,7 +99,8 @@ def test_env_step_vs_oracle_and_golden(golden, sensor, seed, pname):
     assert worst_g["meal"] < 1e-12 and worst_g["insulin"] < 1e-15, worst_g
 
 
-def test_config2_1024_replicas_vs_scipy(golden):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_config2_1024_replicas_vs_scipy(golden, variant):
     """BASELINE config 2: 1 024 replicas of adult#001, random-action policy, 1-min dt, fp64,
     24 h, three meals -- every replica must equal the SciPy golden trace to < 1e-3 mg/dL and
     all replicas must agree bitwise."""
@@ -99,10 +110,8 @@ def test_config2_1024_replicas_vs_scipy(golden):
     names, tab = params.patient_table()
     ip = names.index("adult#001")
     n = 1024
-    env = _env(patient="adult#001", n_envs=n, sensor="Navigator", n_sub=4, seed=3)
     # the G2 traces drive T1DPatient.step directly (no pump): use a pump with a negligible increment
-    env.close()
-    env = _env(patient="adult#001", n_envs=n, sensor="Navigator", n_sub=4, seed=3,
+    env = _env(variant, patient="adult#001", n_envs=n, sensor="Navigator", n_sub=4, seed=3,
                pump_row=np.array([0.0, 1e9, 1e-9, 0.0, 1e9, 1e-9]))
     env.reset()
     cho = np.zeros(1440)
@@ -125,15 +134,17 @@ def test_config2_1024_replicas_vs_scipy(golden):
     assert worst < TOL_SCIPY, worst
 
 
-def test_all_30_patients_24h_vs_scipy_and_oracle(golden):
+@pytest.mark.parametrize("variant", ("ref", "lds"))
+def test_all_30_patients_24h_vs_scipy_and_oracle(golden, variant):
     """G2 for every virtual patient in one batch (heterogeneous patient ids in one wave)."""
     import torch
     from oracle import t1d_oracle as O
     g = golden("g2_openloop.npz")
     names, tab = O.patient_table()
     n = 30
-    env = _env(patient=np.arange(30), sensor="Navigator", n_sub=4,
+    env = _env(variant, patient=np.arange(30), sensor="Navigator", n_sub=4,
                pump_row=np.array([0.0, 1e9, 1e-9, 0.0, 1e9, 1e-9]))
+    assert not env.wave_uniform
     env.reset()
     cho = np.zeros(1440)
     for m, gr in zip(g["meal_minute"], g["meal_grams"]):
