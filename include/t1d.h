@@ -103,6 +103,9 @@ typedef struct t1d_batch {
     uint32_t* meta;           /* [n] packed: patient row | eating flag | meal cursor */
     uint32_t* episode;        /* [n] episode counter, pre-incremented by t1d_reset; separates the Philox
                                  streams of successive episodes of one env.  NULL = always 0 */
+    int32_t* next_meal;       /* [n] minute of the next meal-table entry (INT32_MAX = none), maintained by
+                                 t1d_reset/t1d_step so the common minute needs no table access.  NULL = the
+                                 table row at the cursor is read every minute instead */
     void* last_cgm;           /* [n] sensor zero-order hold (cgm.py:32-36) */
     void* ar_e;               /* [n] AR(1) noise state      (noise_gen.py:86-88) */
     void* pts;                /* [11][n] Johnson-SU points of the current 150-min block */

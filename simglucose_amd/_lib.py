@@ -31,7 +31,7 @@ class Batch(C.Structure):
         ("n", C.c_int64), ("env_offset", C.c_int64), ("dtype", C.c_int32), ("n_meals", C.c_int32),
         ("n_normals", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64),
         ("x", C.c_void_p), ("planned", C.c_void_p), ("last_qsto", C.c_void_p), ("last_food", C.c_void_p),
-        ("t", C.c_void_p), ("meta", C.c_void_p), ("episode", C.c_void_p),
+        ("t", C.c_void_p), ("meta", C.c_void_p), ("episode", C.c_void_p), ("next_meal", C.c_void_p),
         ("last_cgm", C.c_void_p), ("ar_e", C.c_void_p), ("pts", C.c_void_p), ("prev_cgm", C.c_void_p),
         ("basal", C.c_void_p), ("bolus", C.c_void_p), ("cho", C.c_void_p), ("meal_time", C.c_void_p),
         ("meal_amt", C.c_void_p), ("normals", C.c_void_p), ("x0_override", C.c_void_p),

@@ -13,8 +13,8 @@ import torch
 
 from . import _lib, params
 
-_STATE_KEYS = ("x", "planned", "last_qsto", "last_food", "t", "meta", "episode", "last_cgm", "ar_e", "pts",
-               "prev_cgm")
+_STATE_KEYS = ("x", "planned", "last_qsto", "last_food", "t", "meta", "episode", "next_meal", "last_cgm", "ar_e",
+               "pts", "prev_cgm")
 _OUT_KEYS = ("cgm", "bg", "reward", "done", "lbgi", "hbgi", "risk", "meal", "insulin")
 
 
@@ -79,6 +79,7 @@ class BatchedT1DSimEnv:
         self.t = z(n, dt=torch.int32)
         self.meta = torch.from_numpy(pid.astype(np.int32)).to(dv)          # patient row in bits 0-7
         self.episode = z(n, dt=torch.int32)
+        self.next_meal = torch.full((n,), _lib.MEAL_UNUSED, dtype=torch.int32, device=dv)
         self.last_cgm = z(n); self.ar_e = z(n); self.pts = z(11, n); self.prev_cgm = z(n)
         self.cgm = z(n); self.bg = z(n); self.reward = z(n); self.done = z(n, dt=torch.uint8)
         if extra_outputs:
@@ -138,6 +139,9 @@ class BatchedT1DSimEnv:
             raise ValueError("meal tables must both have shape [n_meals, n]")
         self.meal_time, self.meal_amt = mt, ma
         self._b.meal_time, self._b.meal_amt, self._b.n_meals = mt.data_ptr(), ma.data_ptr(), mt.shape[0]
+        # restart the table scan: cursor 0, next entry = row 0 (rows before the current minute are skipped lazily)
+        self.meta.bitwise_and_(0xFFFF)
+        self.next_meal.copy_(mt[0])
 
     def set_option(self, name, value):
         """t1d_ctx_set_option: e.g. ("math", 0) selects the ocml-tanh / IEEE-division RHS variant."""

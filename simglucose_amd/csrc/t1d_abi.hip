@@ -26,7 +26,7 @@ namespace t1d {
 template <typename T> struct KArgs {
     int64_t n, env_offset;
     uint64_t seed;
-    T* x; T* planned; T* last_qsto; T* last_food; int32_t* t; uint32_t* meta; uint32_t* episode;
+    T* x; T* planned; T* last_qsto; T* last_food; int32_t* t; uint32_t* meta; uint32_t* episode; int32_t* next_meal;
     T* last_cgm; T* ar_e; T* pts; T* prev_cgm;
     const T* basal; const T* bolus; const T* cho; const int32_t* meal_time; const T* meal_amt;
     const T* normals; const T* x0_override;
@@ -68,7 +68,7 @@ template <typename U> __device__ __forceinline__ U& at(U* base, unsigned i)
 template <typename T> struct Env {
     T x[13];
     T planned, lq, lf, last_cgm, ar_e, prev_cgm;
-    int t, cursor;
+    int t, cursor, next_meal, next_meal_loaded;
     bool eating;
 };
 template <typename T> struct StepOut { T cgm, bg, meal, ins; };
@@ -89,6 +89,8 @@ __device__ __forceinline__ void load_env(const KArgs<T>& a, unsigned i, uint32_t
     e.planned = at(a.planned, i); e.lq = at(a.last_qsto, i); e.lf = at(a.last_food, i);
     e.last_cgm = at(a.last_cgm, i); e.ar_e = at(a.ar_e, i); e.prev_cgm = at(a.prev_cgm, i);
     e.t = at(a.t, i);
+    e.next_meal = a.next_meal ? at(a.next_meal, i) : 0;
+    e.next_meal_loaded = e.next_meal;
     e.eating = (meta & T1D_META_EATING) != 0;
     e.cursor = (int)T1D_META_CURSOR(meta);
 }
@@ -101,6 +103,7 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
     at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
     at(a.last_cgm, i) = e.last_cgm; at(a.ar_e, i) = e.ar_e; at(a.prev_cgm, i) = e.prev_cgm;
     at(a.t, i) = e.t;
+    if (a.next_meal && e.next_meal != e.next_meal_loaded) at(a.next_meal, i) = e.next_meal;
     at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
 }
 
@@ -108,8 +111,17 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
 // spacing (:84-97) behind the carried-over last point.  Runs once per 150 simulated minutes per env,
 // so it is kept out of line: its registers (ocml sinh, Philox) are paid for on this path only.
 // Returns sample 0 of the new block, W[0] . points.
+#ifndef T1D_REFILL_INLINE
+#define T1D_REFILL_INLINE 1
+#endif
+#if T1D_REFILL_INLINE
+#define T1D_REFILL_ATTR __forceinline__
+#else
+#define T1D_REFILL_ATTR __noinline__
+#endif
+
 template <typename T>
-__device__ __noinline__ T noise_refill(T* __restrict__ pts, const T* __restrict__ normals, const T* __restrict__ w,
+__device__ T1D_REFILL_ATTR T noise_refill(T* __restrict__ pts, const T* __restrict__ normals, const T* __restrict__ w,
                                        const uint32_t* __restrict__ episode, int* status, int64_t n, unsigned i,
                                        int64_t env_offset, uint64_t seed, int n_normals, int b, SensorC<T> sen, T* ar_e)
 {
@@ -160,12 +172,22 @@ __device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, 
     return acc;
 }
 
-// CGMSensor.measure at patient time e.t (cgm.py:26-36); sample index = 1 + t/st after reset used #0,#1.
+// CGMSensor.measure (cgm.py:26-36) split in two so that the memory latency of the noise block hides
+// under the ODE integration: the noise of the sample due at minute t+1 does not depend on the
+// patient state, so it is drawn BEFORE the RK4 sub-steps (sample index = 1 + (t+1)/st: reset used
+// #0 and #1) and added to Gsub after them.
 template <typename T>
-__device__ __forceinline__ T measure(const KArgs<T>& a, unsigned i, Env<T>& e, T gsub)
+__device__ __forceinline__ T measure_noise(const KArgs<T>& a, unsigned i, Env<T>& e, bool& due)
 {
-    if (e.t % a.sen.st == 0) {
-        T cgm = gsub + noise_sample(a, i, 1 + e.t / a.sen.st, e.ar_e);
+    const int t1 = e.t + 1;
+    due = (t1 % a.sen.st) == 0;
+    return due ? noise_sample(a, i, 1 + t1 / a.sen.st, e.ar_e) : T(0);
+}
+template <typename T>
+__device__ __forceinline__ T measure_apply(const KArgs<T>& a, Env<T>& e, T gsub, T noise, bool due)
+{
+    if (due) {
+        T cgm = gsub + noise;
         cgm = cgm > a.sen.vmin ? cgm : a.sen.vmin;
         cgm = cgm < a.sen.vmax ? cgm : a.sen.vmax;
         e.last_cgm = cgm;
@@ -173,12 +195,24 @@ __device__ __forceinline__ T measure(const KArgs<T>& a, unsigned i, Env<T>& e, T
     return e.last_cgm;
 }
 
-// scenario.get_action(time) from the per-env meal table (scenario.py:33-42 / scenario_gen.py:23-31)
+// scenario.get_action(time) from the per-env meal table (scenario.py:33-42 / scenario_gen.py:23-31).
+// With the `next_meal` state array the common minute costs no table access at all: the minute of the
+// next entry travels with the env state and the table is touched only when a meal fires.
 template <typename T>
 __device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& e)
 {
     T meal = T(0);
-    if (e.cursor < a.n_meals) {
+    if (a.next_meal) {
+        if (e.next_meal <= e.t) {                       // rare: a meal fires (or stale entries are skipped)
+            while (e.cursor < a.n_meals) {
+                const int mt = at(rowv(a.meal_time, a.n, e.cursor), i);
+                if (mt > e.t) { e.next_meal = mt; break; }
+                if (mt == e.t) meal = at(rowv(a.meal_amt, a.n, e.cursor), i);
+                ++e.cursor;
+            }
+            if (e.cursor >= a.n_meals) e.next_meal = INT_MAX;
+        }
+    } else if (e.cursor < a.n_meals) {
         int mt = at(rowv(a.meal_time, a.n, e.cursor), i);
         while (mt < e.t && ++e.cursor < a.n_meals) mt = at(rowv(a.meal_time, a.n, e.cursor), i);
         if (e.cursor < a.n_meals && mt == e.t) {
@@ -202,11 +236,13 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
     StepOut<T> o{T(0), T(0), T(0), T(0)};
     for (int m = 0; m < a.minutes; ++m) {
         const T meal = a.cho ? at(row(a.cho, a.n, m), i) : meal_lookup(a, i, e);      // env.py:50
+        bool due;
+        const T noise = measure_noise(a, i, e, due);
         const MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
         rk4_minute<MATH>(p, u, e.x, a.n_sub);
         e.t += 1;
         const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
-        const T cgm = measure(a, i, e, gsub);            // env.py:62
+        const T cgm = measure_apply(a, e, gsub, noise, due);                      // env.py:62
         if (MATH == 0) { o.meal += meal / div; o.ins += insulin / div; o.bg += gsub / div; o.cgm += cgm / div; }   // env.py:78-81
         else { o.meal += meal * inv_div; o.ins += insulin * inv_div; o.bg += gsub * inv_div; o.cgm += cgm * inv_div; }
     }
@@ -364,6 +400,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
         e.x[12] += t_sqrt(T(0.1) * e.x[12]) * (T)r2.x;
     }
     e.planned = T(0); e.lq = e.x[0] + e.x[1]; e.lf = T(0); e.eating = false; e.cursor = 0; e.t = 0;
+    e.next_meal = (a.n_meals > 0) ? at(a.meal_time, i) : INT_MAX;      // first table row; entries before t = 0 are skipped lazily
+    e.next_meal_loaded = e.next_meal - 1;                               // force the store
     // CGMSensor.reset -> CGMNoise(): first AR value and first 15-min point (noise_gen.py:24,86)
     T z0;
     if (a.normals) {
@@ -585,7 +623,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     KArgs<T> a;
     a.n = b->n; a.env_offset = b->env_offset; a.seed = b->seed;
     a.x = (T*)b->x; a.planned = (T*)b->planned; a.last_qsto = (T*)b->last_qsto; a.last_food = (T*)b->last_food;
-    a.t = b->t; a.meta = b->meta; a.episode = b->episode;
+    a.t = b->t; a.meta = b->meta; a.episode = b->episode; a.next_meal = b->next_meal;
     a.last_cgm = (T*)b->last_cgm; a.ar_e = (T*)b->ar_e; a.pts = (T*)b->pts; a.prev_cgm = (T*)b->prev_cgm;
     a.basal = (const T*)b->basal; a.bolus = (const T*)b->bolus; a.cho = (const T*)b->cho;
     a.meal_time = b->meal_time; a.meal_amt = (const T*)b->meal_amt;
