@@ -108,7 +108,8 @@ typedef struct t1d_batch {
                                  table row at the cursor is read every minute instead */
     void* last_cgm;           /* [n] sensor zero-order hold (cgm.py:32-36) */
     void* ar_e;               /* [n] AR(1) noise state      (noise_gen.py:86-88) */
-    void* pts;                /* [11][n] Johnson-SU points of the current 150-min block */
+    void* pts;                /* [26][n] CGM-noise spline of the current 150-min block: rows 0-10 the Johnson-SU
+                                 points, 11-21 their knot second derivatives, 22-25 the current 15-min interval */
     void* prev_cgm;           /* [n] CGM_hist[-1] (default reward, env.py:27-33) */
     /* ---- inputs */
     const void* basal;        /* [n] U/min */
@@ -144,12 +145,11 @@ int t1d_abi_version(void);
 const char* t1d_last_error(void);
 
 /* Build the constant tables of one device.  patient_table: [n_patients][n_cols] (T1D_P_* order,
- * n_cols == T1D_P_NCOLS), sensor_row [T1D_SENSOR_NCOLS], pump_row [T1D_PUMP_NCOLS], spline_W
- * [w_rows][11] = the cubic-spline block operator of the CGM noise (noise_gen.py:45-47), all host
- * doubles, copied.  sample_time must be a positive integer number of minutes. */
+ * n_cols == T1D_P_NCOLS), sensor_row [T1D_SENSOR_NCOLS], pump_row [T1D_PUMP_NCOLS], all host
+ * doubles, copied.  sample_time must be a whole number of minutes in [1, 150].  The cubic-spline
+ * interpolation of the CGM noise (noise_gen.py:38-47) is built inside the library. */
 int t1d_ctx_create(int hip_device, const double* patient_table, int n_patients, int n_cols,
-                   const double* sensor_row, const double* pump_row, const double* spline_W,
-                   int w_rows, t1d_ctx** out);
+                   const double* sensor_row, const double* pump_row, t1d_ctx** out);
 int t1d_ctx_destroy(t1d_ctx* ctx);
 
 /* Tuning/diagnostic switches.  "math": 1 (default) = exp-based gastric-emptying term and

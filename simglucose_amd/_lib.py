@@ -82,7 +82,7 @@ def lib():
     dp = C.POINTER(C.c_double)
     L.t1d_abi_version.restype = C.c_int
     L.t1d_last_error.restype = C.c_char_p
-    L.t1d_ctx_create.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.POINTER(vp)]
+    L.t1d_ctx_create.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, dp, C.POINTER(vp)]
     L.t1d_ctx_destroy.argtypes = [vp]
     L.t1d_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
     L.t1d_reset.argtypes = [vp, C.POINTER(Batch), vp, C.c_int, vp]

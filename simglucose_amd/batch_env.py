@@ -64,7 +64,6 @@ class BatchedT1DSimEnv:
         self.pump_row = np.asarray(pump_row if pump_row is not None else params.pump_row(pump), dtype=np.float64)
         self.sample_time = float(self.sensor_row[5])
         self.minutes_per_step = int(self.sample_time)
-        self.W = np.ascontiguousarray(params.spline_block_operator(self.sample_time))
 
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._ctx = C.c_void_p()
@@ -72,7 +71,7 @@ class BatchedT1DSimEnv:
         tab = np.ascontiguousarray(self.table)
         _lib.check(self._L.t1d_ctx_create(dev_index, tab.ctypes.data_as(dp), tab.shape[0], tab.shape[1],
                                           self.sensor_row.ctypes.data_as(dp), self.pump_row.ctypes.data_as(dp),
-                                          self.W.ctypes.data_as(dp), self.W.shape[0], C.byref(self._ctx)))
+                                          C.byref(self._ctx)))
         n, dv, ft = self.n, self.device, dtype
         z = lambda *shape, dt=ft: torch.zeros(*shape, dtype=dt, device=dv)
         self.x = z(13, n); self.planned = z(n); self.last_qsto = z(n); self.last_food = z(n)
@@ -80,7 +79,7 @@ class BatchedT1DSimEnv:
         self.meta = torch.from_numpy(pid.astype(np.int32)).to(dv)          # patient row in bits 0-7
         self.episode = z(n, dt=torch.int32)
         self.next_meal = torch.full((n,), _lib.MEAL_UNUSED, dtype=torch.int32, device=dv)
-        self.last_cgm = z(n); self.ar_e = z(n); self.pts = z(11, n); self.prev_cgm = z(n)
+        self.last_cgm = z(n); self.ar_e = z(n); self.pts = z(26, n); self.prev_cgm = z(n)
         self.cgm = z(n); self.bg = z(n); self.reward = z(n); self.done = z(n, dt=torch.uint8)
         if extra_outputs:
             self.lbgi = z(n); self.hbgi = z(n); self.risk = z(n); self.meal = z(n); self.insulin = z(n)

@@ -33,7 +33,7 @@ template <typename T> struct KArgs {
     T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin;
     const T* dpar;          // [DP_COUNT][kMaxPatients] derived patient constants
     const double* x0tab;    // [13][np]
-    const T* W;             // [S][11]
+    const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
     int* status;
     SensorC<T> sen; PumpC<T> pump;
     int np, S, n_meals, n_normals, minutes, n_sub;
@@ -67,7 +67,8 @@ template <typename U> __device__ __forceinline__ U& at(U* base, unsigned i)
 // env state held in registers across the minutes of a launch
 template <typename T> struct Env {
     T x[13];
-    T planned, lq, lf, last_cgm, ar_e, prev_cgm;
+    T planned, lq, lf, last_cgm, prev_cgm;
+    T cur[4];           // current 15-min interval of the noise spline (pts rows 22..25)
     int t, cursor, next_meal, next_meal_loaded;
     bool eating;
 };
@@ -87,7 +88,9 @@ __device__ __forceinline__ void load_env(const KArgs<T>& a, unsigned i, uint32_t
 #pragma unroll
     for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
     e.planned = at(a.planned, i); e.lq = at(a.last_qsto, i); e.lf = at(a.last_food, i);
-    e.last_cgm = at(a.last_cgm, i); e.ar_e = at(a.ar_e, i); e.prev_cgm = at(a.prev_cgm, i);
+    e.last_cgm = at(a.last_cgm, i); e.prev_cgm = at(a.prev_cgm, i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.pts, a.n, 22 + k), i);
     e.t = at(a.t, i);
     e.next_meal = a.next_meal ? at(a.next_meal, i) : 0;
     e.next_meal_loaded = e.next_meal;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
 #pragma unroll
     for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
     at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
-    at(a.last_cgm, i) = e.last_cgm; at(a.ar_e, i) = e.ar_e; at(a.prev_cgm, i) = e.prev_cgm;
+    at(a.last_cgm, i) = e.last_cgm; at(a.prev_cgm, i) = e.prev_cgm;
     at(a.t, i) = e.t;
     if (a.next_meal && e.next_meal != e.next_meal_loaded) at(a.next_meal, i) = e.next_meal;
     at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
@@ -111,6 +114,17 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
 // spacing (:84-97) behind the carried-over last point.  Runs once per 150 simulated minutes per env,
 // so it is kept out of line: its registers (ocml sinh, Philox) are paid for on this path only.
 // Returns sample 0 of the new block, W[0] . points.
+// ---- CGM noise (sensor/noise_gen.py) ----------------------------------------------------------------
+// The reference interpolates each block of 11 Johnson-SU points (15-min spacing, 150 min) with
+// scipy's interp1d(kind='cubic') = the not-a-knot cubic spline, and hands out its values on the sensor
+// grid (noise_gen.py:38-47).  That spline is evaluated here in its local form instead of as a dense
+// 11-tap operator per sample: with M = second derivatives at the knots (M = Minv . y, Minv fixed),
+//   S(tau) = A y_m + B y_{m+1} + ((A^3 - A) M_m + (B^3 - B) M_{m+1}) h^2/6,  A = (t_{m+1} - tau)/h, B = 1 - A,
+// so a sample reads 4 words (rows 22..25 of `pts`, the current interval) instead of 11 + 11, and the
+// rows it reads do not depend on the env's clock (they can be fetched with the rest of the state).
+// pts rows: 0..10 = y (points of the block), 11..21 = M, 22..25 = (y_m, y_{m+1}, M_m, M_{m+1}).
+constexpr int kPtsRows = 26;
+
 #ifndef T1D_REFILL_INLINE
 #define T1D_REFILL_INLINE 1
 #endif
@@ -120,14 +134,18 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
 #define T1D_REFILL_ATTR __noinline__
 #endif
 
+// Refill of the CGM noise deque (noise_gen.py:30-56): ten new AR(1) -> Johnson-SU points behind the
+// carried-over last point (:84-97), then the knot second derivatives.  Once per 150 simulated minutes.
 template <typename T>
-__device__ T1D_REFILL_ATTR T noise_refill(T* __restrict__ pts, const T* __restrict__ normals, const T* __restrict__ w,
-                                       const uint32_t* __restrict__ episode, int* status, int64_t n, unsigned i,
-                                       int64_t env_offset, uint64_t seed, int n_normals, int b, SensorC<T> sen, T* ar_e)
+__device__ T1D_REFILL_ATTR void noise_refill(T* __restrict__ pts, const T* __restrict__ normals, const T* __restrict__ minv,
+                                             const uint32_t* __restrict__ episode, int* status, int64_t n, unsigned i,
+                                             int64_t env_offset, uint64_t seed, int n_normals, int b, SensorC<T> sen, T* ar_e)
 {
-    const T p0 = at(rowv(pts, n, b > 0 ? 10 : 0), i);          // carried-over last point (:33,36)
+    const T p0 = at(rowv(pts, n, b > 0 ? 10 : 0), i);    // carried-over last point (:33,36)
     at(pts, i) = p0;
-    T acc = w[0] * p0;
+    T M[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) M[k] = minv[k * 11] * p0;
     T e = *ar_e;
     const uint32_t ep = (!normals && episode) ? at(episode, i) : 0u;
 #pragma unroll 1
@@ -142,34 +160,44 @@ __device__ T1D_REFILL_ATTR T noise_refill(T* __restrict__ pts, const T* __restri
             z0 = (T)r.x; z1 = (T)r.y;
         }
         e = sen.pacf * (e + z0);                         // :88
-        T v = johnson_su<true>(sen, e);
-        at(rowv(pts, n, 2 * q + 1), i) = v; acc += w[2 * q + 1] * v;
+        const T ya = johnson_su<true>(sen, e);
         e = sen.pacf * (e + z1);
-        v = johnson_su<true>(sen, e);
-        at(rowv(pts, n, 2 * q + 2), i) = v; acc += w[2 * q + 2] * v;
+        const T yb = johnson_su<true>(sen, e);
+        at(rowv(pts, n, 2 * q + 1), i) = ya;
+        at(rowv(pts, n, 2 * q + 2), i) = yb;
+        const T* mc = minv + (2 * q + 1);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) M[k] += mc[k * 11] * ya + mc[k * 11 + 1] * yb;
     }
     *ar_e = e;
-    return acc;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) at(rowv(pts, n, 11 + k), i) = M[k];
 }
 
-// next(CGMNoise) for sample index s (noise_gen.py:61-69).
+// next(CGMNoise) for sample index s (noise_gen.py:61-69).  cur = rows 22..25 of pts as loaded with the
+// env state; updated (and stored) when the sample enters a new 15-minute interval.
 template <typename T>
-__device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, T& ar_e)
+__device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, T (&cur)[4])
 {
     const int64_t n = a.n;
+    const int st = a.sen.st;
     const int j = s % a.S, b = s / a.S;
-    const T* w = a.W + j * 11;
-    T acc;
+    const int tau = (j + 1) * st;
+    const int m = tau / 15 < 9 ? tau / 15 : 9;
+    const int mprev = (tau - st) / 15 < 9 ? (tau - st) / 15 : 9;
     if (j == 0) {                       // deque empty: build the next 150-minute block
-        T e = ar_e;
-        acc = noise_refill<T>(a.pts, a.normals, w, a.episode, a.status, n, i, a.env_offset, a.seed, a.n_normals, b, a.sen, &e);
-        ar_e = e;
-    } else {
-        acc = T(0);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) acc += w[k] * at(row(a.pts, n, k), i);
+        T e = at(a.ar_e, i);            // the AR(1) state is touched by refills only
+        noise_refill<T>(a.pts, a.normals, a.minv, a.episode, a.status, n, i, a.env_offset, a.seed, a.n_normals, b, a.sen, &e);
+        at(a.ar_e, i) = e;
     }
-    return acc;
+    if (j == 0 || m != mprev) {         // entering interval m: fetch its knots (every 15 minutes)
+        cur[0] = at(rowv(a.pts, n, m), i);      cur[1] = at(rowv(a.pts, n, m + 1), i);
+        cur[2] = at(rowv(a.pts, n, 11 + m), i); cur[3] = at(rowv(a.pts, n, 12 + m), i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) at(row(a.pts, n, 22 + k), i) = cur[k];
+    }
+    const T B = T(tau - 15 * m) * T(1.0 / 15.0), A = T(1) - B;
+    return A * cur[0] + B * cur[1] + T(37.5) * ((A * A * A - A) * cur[2] + (B * B * B - B) * cur[3]);
 }
 
 // CGMSensor.measure (cgm.py:26-36) split in two so that the memory latency of the noise block hides
@@ -181,7 +209,7 @@ __device__ __forceinline__ T measure_noise(const KArgs<T>& a, unsigned i, Env<T>
 {
     const int t1 = e.t + 1;
     due = (t1 % a.sen.st) == 0;
-    return due ? noise_sample(a, i, 1 + t1 / a.sen.st, e.ar_e) : T(0);
+    return due ? noise_sample(a, i, 1 + t1 / a.sen.st, e.cur) : T(0);
 }
 template <typename T>
 __device__ __forceinline__ T measure_apply(const KArgs<T>& a, Env<T>& e, T gsub, T noise, bool due)
@@ -409,14 +437,14 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
     } else {
         z0 = (T)philox_pair(a.seed, gid, ep, 0u).x;
     }
-    e.ar_e = z0;
+    at(a.ar_e, i) = z0;
     at(a.pts, i) = johnson_su<true>(a.sen, z0);
     e.last_cgm = T(0);
     const T vg = a.dpar[DP_VG * kMaxPatients + pid];
     const T bg0 = e.x[12] / vg;
     T c[2];
     for (int s = 0; s < 2; ++s) {                    // env.py:126 (history[0]) and env.py:142 (observation)
-        T v = bg0 + noise_sample(a, i, s, e.ar_e);
+        T v = bg0 + noise_sample(a, i, s, e.cur);
         v = v > a.sen.vmin ? v : a.sen.vmin;
         v = v < a.sen.vmax ? v : a.sen.vmax;
         c[s] = v;
@@ -465,7 +493,7 @@ struct t1d_ctx {
     double pump[T1D_PUMP_NCOLS];
     double* d_par64 = nullptr; float* d_par32 = nullptr;
     double* d_x0 = nullptr;
-    double* d_W64 = nullptr; float* d_W32 = nullptr;
+    double* d_minv64 = nullptr; float* d_minv32 = nullptr;
     int* d_status = nullptr;
     int math = 1;            // RHS arithmetic variant (t1d_ctx_set_option "math")
     int scalar_params = 1;   // allow the SGPR-parameter kernels for wave-uniform batches
@@ -481,24 +509,55 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(T1D_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e));        \
     } while (0)
 
+// Minv [11][11] with M = Minv . y: second derivatives at the knots of the not-a-knot cubic spline
+// through 11 points at 15-minute spacing -- what scipy's interp1d(kind='cubic') builds in
+// noise_gen.py:45.  Interior rows: M[k-1] + 4 M[k] + M[k+1] = 6 (y[k-1] - 2 y[k] + y[k+1]) / h^2; the two
+// not-a-knot rows make the third derivative continuous at the first and last interior knots.
+static std::vector<double> spline_second_derivative_operator()
+{
+    const int K = 11;
+    const double h = 15.0;
+    std::vector<double> A(K * K, 0.0), B(K * K, 0.0);
+    for (int k = 1; k < K - 1; ++k) {
+        A[k * K + k - 1] = 1.0; A[k * K + k] = 4.0; A[k * K + k + 1] = 1.0;
+        B[k * K + k - 1] = 6.0 / (h * h); B[k * K + k] = -12.0 / (h * h); B[k * K + k + 1] = 6.0 / (h * h);
+    }
+    A[0] = 1.0; A[1] = -2.0; A[2] = 1.0;
+    A[(K - 1) * K + K - 3] = 1.0; A[(K - 1) * K + K - 2] = -2.0; A[(K - 1) * K + K - 1] = 1.0;
+    // Gauss-Jordan with partial pivoting on [A | B]
+    for (int c = 0; c < K; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < K; ++r) if (std::fabs(A[r * K + c]) > std::fabs(A[piv * K + c])) piv = r;
+        if (piv != c) for (int j = 0; j < K; ++j) { std::swap(A[c * K + j], A[piv * K + j]); std::swap(B[c * K + j], B[piv * K + j]); }
+        const double d = A[c * K + c];
+        for (int j = 0; j < K; ++j) { A[c * K + j] /= d; B[c * K + j] /= d; }
+        for (int r = 0; r < K; ++r) {
+            if (r == c) continue;
+            const double f = A[r * K + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < K; ++j) { A[r * K + j] -= f * A[c * K + j]; B[r * K + j] -= f * B[c * K + j]; }
+        }
+    }
+    return B;
+}
+
 extern "C" int t1d_abi_version(void) { return T1D_ABI_VERSION; }
 extern "C" const char* t1d_last_error(void) { return g_err.c_str(); }
 
 extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients, int n_cols,
-                              const double* sensor_row, const double* pump_row, const double* W, int w_rows,
-                              t1d_ctx** out)
+                              const double* sensor_row, const double* pump_row, t1d_ctx** out)
 {
     try {
         if (!out) return fail(T1D_E_INVALID, "t1d_ctx_create: out is NULL");
         *out = nullptr;
-        if (!ptab || !sensor_row || !pump_row || !W) return fail(T1D_E_INVALID, "t1d_ctx_create: NULL table");
+        if (!ptab || !sensor_row || !pump_row) return fail(T1D_E_INVALID, "t1d_ctx_create: NULL table");
         if (n_cols != T1D_P_NCOLS) return fail(T1D_E_INVALID, "t1d_ctx_create: n_cols must be T1D_P_NCOLS (45)");
         if (n_patients < 1 || n_patients > kMaxPatients)
             return fail(T1D_E_INVALID, "t1d_ctx_create: n_patients must be in [1, 64]");
         const double st = sensor_row[5];
         if (!(st >= 1.0) || st != std::floor(st) || st > 1440.0)
             return fail(T1D_E_INVALID, "t1d_ctx_create: sensor sample_time must be a whole number of minutes >= 1");
-        if (w_rows < 1) return fail(T1D_E_INVALID, "t1d_ctx_create: w_rows must be >= 1");
+        if (st > 150.0) return fail(T1D_E_INVALID, "t1d_ctx_create: sensor sample_time must be <= 150 minutes");
         for (int k = 2; k < 6; k += 3)
             if (!(pump_row[k] > 0.0)) return fail(T1D_E_INVALID, "t1d_ctx_create: pump increments must be > 0");
         int ndev = 0;
@@ -509,7 +568,7 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
 
         t1d_ctx* c = new (std::nothrow) t1d_ctx();
         if (!c) return fail(T1D_E_INVALID, "t1d_ctx_create: out of host memory");
-        c->device = hip_device; c->np = n_patients; c->S = w_rows;
+        c->device = hip_device; c->np = n_patients; c->S = (int)std::floor(150.0 / st);   // noise_gen.py:41-42
         std::memcpy(c->sensor, sensor_row, sizeof(c->sensor));
         std::memcpy(c->pump, pump_row, sizeof(c->pump));
 
@@ -537,7 +596,8 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
             for (int k = 0; k < 13; ++k) x0[(size_t)k * np + j] = r[T1D_P_X0 + k];
         }
         std::vector<float> dpf(dp.begin(), dp.end());
-        std::vector<float> Wf(W, W + (size_t)w_rows * 11);
+        const std::vector<double> minv = spline_second_derivative_operator();
+        std::vector<float> minvf(minv.begin(), minv.end());
         auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
             hipError_t e = hipMalloc(dst, bytes);
             if (e != hipSuccess) return e;
@@ -547,8 +607,8 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
         if (e == hipSuccess) e = up((void**)&c->d_par64, dp.data(), dp.size() * 8);
         if (e == hipSuccess) e = up((void**)&c->d_par32, dpf.data(), dpf.size() * 4);
         if (e == hipSuccess) e = up((void**)&c->d_x0, x0.data(), x0.size() * 8);
-        if (e == hipSuccess) e = up((void**)&c->d_W64, W, (size_t)w_rows * 11 * 8);
-        if (e == hipSuccess) e = up((void**)&c->d_W32, Wf.data(), Wf.size() * 4);
+        if (e == hipSuccess) e = up((void**)&c->d_minv64, minv.data(), minv.size() * 8);
+        if (e == hipSuccess) e = up((void**)&c->d_minv32, minvf.data(), minvf.size() * 4);
         if (e == hipSuccess) e = hipMalloc((void**)&c->d_status, sizeof(int));
         if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(int));
         if (e != hipSuccess) {
@@ -591,7 +651,7 @@ extern "C" int t1d_ctx_destroy(t1d_ctx* c)
     if (!c) return T1D_OK;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_par64); (void)hipFree(c->d_par32); (void)hipFree(c->d_x0);
-    (void)hipFree(c->d_W64); (void)hipFree(c->d_W32); (void)hipFree(c->d_status);
+    (void)hipFree(c->d_minv64); (void)hipFree(c->d_minv32); (void)hipFree(c->d_status);
     delete c;
     return T1D_OK;
 }
@@ -633,7 +693,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.lbgi = (T*)b->lbgi; a.hbgi = (T*)b->hbgi; a.risk = (T*)b->risk; a.meal = (T*)b->meal; a.insulin = (T*)b->insulin;
     a.dpar = sizeof(T) == 8 ? (const T*)c->d_par64 : (const T*)c->d_par32;
     a.x0tab = c->d_x0;
-    a.W = sizeof(T) == 8 ? (const T*)c->d_W64 : (const T*)c->d_W32;
+    a.minv = sizeof(T) == 8 ? (const T*)c->d_minv64 : (const T*)c->d_minv32;
     a.status = c->d_status;
     a.sen.pacf = (T)c->sensor[0]; a.sen.gamma = (T)c->sensor[1]; a.sen.lambda = (T)c->sensor[2];
     a.sen.delta = (T)c->sensor[3]; a.sen.xi = (T)c->sensor[4]; a.sen.st = (int)c->sensor[5];

@@ -34,18 +34,18 @@ def test_ctx_create_rejects_bad_arguments_without_touching_a_gpu():
     tab = np.ascontiguousarray(tab)
     dp = C.POINTER(C.c_double)
     sen = params.sensor_row("Dexcom"); pump = params.pump_row("Insulet")
-    W = np.ascontiguousarray(params.spline_block_operator(3.0))
     ctx = C.c_void_p()
 
-    def create(n_cols=45, npat=30, sensor=sen, w_rows=W.shape[0]):
+    def create(n_cols=45, npat=30, sensor=sen):
         return L.t1d_ctx_create(0, tab.ctypes.data_as(dp), npat, n_cols, sensor.ctypes.data_as(dp),
-                                pump.ctypes.data_as(dp), W.ctypes.data_as(dp), w_rows, C.byref(ctx))
+                                pump.ctypes.data_as(dp), C.byref(ctx))
     assert create(n_cols=44) == -1 and b"n_cols" in L.t1d_last_error()
     assert create(npat=0) == -1
     assert create(npat=65) == -1
     bad = sen.copy(); bad[5] = 2.5
     assert create(sensor=bad) == -1 and b"sample_time" in L.t1d_last_error()
-    assert create(w_rows=0) == -1
+    bad2 = sen.copy(); bad2[5] = 151.0
+    assert create(sensor=bad2) == -1
     assert L.t1d_step(None, None, 1, 4, None) == -1
     assert L.t1d_sync(None, None, None) == -1
     import torch

