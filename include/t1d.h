@@ -94,7 +94,11 @@ typedef struct t1d_batch {
     int32_t n_normals;        /* rows of `normals` (0 = draw in-kernel with Philox) */
     int32_t flags;            /* T1D_BATCH_* */
     uint64_t seed;            /* Philox key */
-    /* ---- state (read + written by t1d_step; written by t1d_reset) */
+    /* ---- state (read + written by t1d_step; written by t1d_reset).
+     * PACKED layout (recommended; detected from the pointers): x, planned, last_qsto, last_food, last_cgm,
+     * prev_cgm, pts are consecutive rows of ONE [44][n] buffer in that order, and t, meta, next_meal are
+     * consecutive rows of one [3][n] int32 buffer.  With it (and n a multiple of 256) t1d_step runs the
+     * persistent kernel that streams the next tile of envs into LDS while it integrates the current one. */
     void* x;                  /* [13][n] ODE state */
     void* planned;            /* [n] planned_meal, g        (t1dpatient.py:229) */
     void* last_qsto;          /* [n] mg                     (t1dpatient.py:90)  */
@@ -155,8 +159,15 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
 /* Tuning/diagnostic switches.  "math": 1 (default) = exp-based gastric-emptying term and
  * Newton-refined reciprocals in the ODE right-hand side; 0 = ocml tanh and IEEE divisions written
  * exactly as t1dpatient.py:138-140,171,178 writes them (A/B and parity reference).
- * "scalar_params": 1 (default) = batches flagged T1D_BATCH_WAVE_UNIFORM use the kernels that keep
- * the patient row in scalar registers; 0 = always read parameters from the LDS table. */
+ * "params_mode": where the ODE parameters live during the RK4 loop: 0 = re-read from the LDS table at
+ * every use, 1 = gathered once per launch into vector registers, -1 (default) = 0 for launches of up to
+ * 3 minutes and 1 for longer ones (the measured cross-over).
+ * "scalar_params": 1 = batches flagged T1D_BATCH_WAVE_UNIFORM keep the patient row in scalar registers
+ * (default 0: measured no faster than the VGPR form).
+ * "pipeline": 1 = t1d_step runs the persistent kernel that streams the next tile of envs into LDS with
+ * LDS-DMA while it integrates the current one (needs the packed state layout and n % 256 == 0);
+ * default 0 (one 256-env tile per workgroup): measured equal within noise in round 1.
+ * "pipe_blocks": grid of the persistent kernel (0 = 2 x compute units). */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after

@@ -74,12 +74,17 @@ class BatchedT1DSimEnv:
                                           C.byref(self._ctx)))
         n, dv, ft = self.n, self.device, dtype
         z = lambda *shape, dt=ft: torch.zeros(*shape, dtype=dt, device=dv)
-        self.x = z(13, n); self.planned = z(n); self.last_qsto = z(n); self.last_food = z(n)
-        self.t = z(n, dt=torch.int32)
-        self.meta = torch.from_numpy(pid.astype(np.int32)).to(dv)          # patient row in bits 0-7
-        self.episode = z(n, dt=torch.int32)
-        self.next_meal = torch.full((n,), _lib.MEAL_UNUSED, dtype=torch.int32, device=dv)
-        self.last_cgm = z(n); self.ar_e = z(n); self.pts = z(26, n); self.prev_cgm = z(n)
+        # packed state (include/t1d.h): one [44, n] float buffer and one [4, n] int32 buffer; the named
+        # tensors are views, so every staged row is one base pointer plus a 32-bit offset on the device
+        self.state = z(44, n)
+        self.x = self.state[0:13]; self.planned = self.state[13]; self.last_qsto = self.state[14]
+        self.last_food = self.state[15]; self.last_cgm = self.state[16]; self.prev_cgm = self.state[17]
+        self.pts = self.state[18:44]
+        self.istate = z(4, n, dt=torch.int32)
+        self.t = self.istate[0]; self.meta = self.istate[1]; self.next_meal = self.istate[2]; self.episode = self.istate[3]
+        self.meta.copy_(torch.from_numpy(pid.astype(np.int32)))            # patient row in bits 0-7
+        self.next_meal.fill_(_lib.MEAL_UNUSED)
+        self.ar_e = z(n)
         self.cgm = z(n); self.bg = z(n); self.reward = z(n); self.done = z(n, dt=torch.uint8)
         if extra_outputs:
             self.lbgi = z(n); self.hbgi = z(n); self.risk = z(n); self.meal = z(n); self.insulin = z(n)

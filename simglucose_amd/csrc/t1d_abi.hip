@@ -252,9 +252,14 @@ __device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& 
 }
 
 // T1DSimEnv.step body (env.py:66-84): `minutes` mini_steps with one action.
-template <int MATH, typename T, typename P>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `pre_rk4` runs once, immediately before the first minute's RK4 sub-steps: from there to the end of
+// the integration the wave issues no vector-memory instruction, which is where the persistent kernel
+// starts the LDS-DMA of its next tile.
+template <int MATH, typename T, typename P, typename Hook = NoHook>
 __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
-                                                T basal, T bolus, bool has_bolus)
+                                                T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook())
 {
     const T q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
     T q_bolus = a.pump.min_bolus > T(0) ? a.pump.min_bolus : T(0);     // = pump.bolus(0)
@@ -266,7 +271,18 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
         const T meal = a.cho ? at(row(a.cho, a.n, m), i) : meal_lookup(a, i, e);      // env.py:50
         bool due;
         const T noise = measure_noise(a, i, e, due);
-        const MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+        MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+        // every load this minute issued is needed by the integration anyway: drain them HERE, on every
+        // path, so that the compiler's own wait cannot land behind the hook's (invisible) DMA instructions
+        p.pin();
+        {   // volatile asms keep their order: everything the RK4 loop consumes is computed (and any spilled
+            // operand reloaded) BEFORE the hook below issues its DMA
+            T aa = u.aa, cc = u.cc, bD = u.bD, dD = u.dD, dmg = u.d_mg, ins = u.ins;
+            asm volatile("" : "+v"(aa), "+v"(cc), "+v"(bD), "+v"(dD), "+v"(dmg), "+v"(ins));
+            u.aa = aa; u.cc = cc; u.bD = bD; u.dD = dD; u.d_mg = dmg; u.ins = ins;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+        if (m == 0) pre_rk4();
         rk4_minute<MATH>(p, u, e.x, a.n_sub);
         e.t += 1;
         const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
@@ -337,6 +353,161 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     }
     write_outputs<MATH>(a, i, e, o);
     store_env(a, i, pid, e);
+}
+
+// ---- persistent, software-pipelined step ---------------------------------------------------------
+// One-tile-per-block launches keep the two waves of a SIMD in lock-step: both wait for their loads,
+// then both compete for the VALU, then both store, so the chip alternates between an idle VALU and an
+// idle memory system (measured: ~60-90 us of a 150-170 us launch at 1 Mi envs).  Here each block walks
+// tiles blockIdx.x, +gridDim.x, ... and every wave streams the state of its NEXT 64 envs from HBM
+// straight into a wave-private LDS staging area with LDS-DMA (global_load_lds_dwordx4: no VGPR is
+// held by data in flight) while it integrates the current 64.  Nothing but the issuing wave's vmcnt
+// orders a ds_read behind a pending LDS-DMA, hence the explicit waits.
+typedef __attribute__((address_space(1))) const void t1d_gptr;
+typedef __attribute__((address_space(3))) void t1d_lptr;
+
+// The pipelined kernel needs the per-env state PACKED: one [44][n] buffer of T (rows 0-12 x, 13 planned,
+// 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_cgm, 18-43 pts) and one [3+][n] int buffer (t, meta,
+// next_meal), so that every staged row is `base + 32-bit offset` (t1d_step checks the pointers and
+// falls back to step_kernel otherwise).  Stage rows: 0-17 = state rows 0-17, 18-21 = pts rows 22-25
+// (state rows 40-43), 22.. = basal, 22+G.. = bolus (each DMA group fetches G rows: 2 for double, 4 for float).
+constexpr int kPackedRows = 18 + kPtsRows;            // 44
+template <typename T> struct StageGeom {
+    static constexpr int EPL = 16 / (int)sizeof(T);   // elements per lane per DMA
+    static constexpr int LPR = 64 / EPL;              // lanes per 64-element row
+    static constexpr int G = 64 / LPR;                // rows per DMA instruction (2 / 4)
+    static constexpr int BASAL = 24;                  // first stage row of the basal group
+    static constexpr int BOLUS = BASAL + G;
+    static constexpr int ROWS = BOLUS + G;
+};
+template <typename T> struct Stage {
+    T f[StageGeom<T>::ROWS][64];
+    int i[4][64];
+};
+
+// One LDS-DMA: lane l fetches 16 B at base + voff; the 1 KiB lands contiguously at lds_dst (M0).
+// Issued through inline asm on purpose: when hipcc knows about a pending LDS-DMA it puts an
+// `s_waitcnt vmcnt(0)` in front of EVERY later LDS read (here: the parameter table inside the RK4
+// loop), which serialises the prefetch with the arithmetic it is meant to hide under.  The loop in
+// step_pipe_kernel counts and waits for these operations itself.
+__device__ __forceinline__ void dma16(const void* base_uniform, unsigned voff, void* lds_dst)
+{
+    const unsigned lds_addr = (unsigned)(size_t)(t1d_lptr*)lds_dst;
+    unsigned saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "v"(voff), "s"(base_uniform), "s"(lds_addr) : "memory");
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_tile(const KArgs<T>& a, unsigned elem0, Stage<T>* st)
+{
+    using GEO = StageGeom<T>;
+    unsigned lane = threadIdx.x & 63u;
+    asm volatile("" : "+v"(lane));       // recompute the few offsets here: hoisted out of the tile loop they get spilled,
+                                         // and a scratch reload between two DMAs is a vmcnt(0) that waits for the first
+    const unsigned rowb = (unsigned)a.n * (unsigned)sizeof(T);                       // bytes per state row
+    const unsigned v0 = elem0 * (unsigned)sizeof(T) + (lane / GEO::LPR) * rowb + (lane % GEO::LPR) * 16u;
+    const void* xb = a.x;
+#pragma unroll
+    for (int r = 0; r < 18; r += GEO::G) dma16(xb, v0 + (unsigned)r * rowb, &st->f[r][0]);   // rows 0..17 (+ spill-over into 18, 19 for float)
+#pragma unroll
+    for (int r = 0; r < 4; r += GEO::G) dma16(xb, v0 + (unsigned)(40 + r) * rowb, &st->f[20 + r][0]);
+    const unsigned vsame = elem0 * (unsigned)sizeof(T) + (lane % GEO::LPR) * 16u;  // every row group = the same row
+    dma16(a.basal, vsame, &st->f[GEO::BASAL][0]);
+    if (a.bolus) dma16(a.bolus, vsame, &st->f[GEO::BOLUS][0]);
+    const unsigned rowi = (unsigned)a.n * 4u;
+    const unsigned li = lane / 16u;
+    dma16(a.t, elem0 * 4u + (li < 3u ? li : 0u) * rowi + (lane % 16u) * 16u, &st->i[0][0]);
+}
+
+template <typename T>
+__device__ __forceinline__ void unstage(const KArgs<T>& a, const Stage<T>* st, Env<T>& e, T& basal, T& bolus, uint32_t& meta)
+{
+    using GEO = StageGeom<T>;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) e.x[k] = st->f[k][lane];
+    e.planned = st->f[13][lane]; e.lq = st->f[14][lane]; e.lf = st->f[15][lane];
+    e.last_cgm = st->f[16][lane]; e.prev_cgm = st->f[17][lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.cur[k] = st->f[20 + k][lane];
+    basal = st->f[GEO::BASAL][lane];
+    bolus = a.bolus ? st->f[GEO::BOLUS][lane] : T(0);
+    e.t = st->i[0][lane];
+    meta = (uint32_t)st->i[1][lane];
+    e.next_meal = st->i[2][lane];
+    e.next_meal_loaded = e.next_meal;
+    e.eating = (meta & T1D_META_EATING) != 0;
+    e.cursor = (int)T1D_META_CURSOR(meta);
+}
+
+// requires a.n % kBlock == 0 and the packed state layout (the host falls back to step_kernel otherwise)
+template <int VARIANT, typename T>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void step_pipe_kernel(const KArgs<T> a)
+{
+    constexpr int MATH = 1;
+    __shared__ T lds[VARIANT == 2 ? 1 : DP_COUNT * kMaxPatients];
+    __shared__ Stage<T> stage[kBlock / 64];
+    if (VARIANT != 2) stage_pars(a, lds);
+    const unsigned ntiles = (unsigned)(a.n / kBlock);
+    unsigned tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Stage<T>* st = &stage[wave];
+    stage_tile(a, tile * kBlock + (unsigned)wave * 64u, st);
+    bool first = true;
+    for (;;) {
+        const unsigned i = tile * kBlock + threadIdx.x;
+        __builtin_assume(i < (1u << 28));
+        Env<T> e;
+        T basal, bolus;
+        uint32_t meta;
+        // This tile's DMA must have landed.  vmcnt retires in order and the DMA is OLDER than everything the
+        // previous tile issued afterwards, of which at least kTileStores are unconditional stores
+        // (x[13], planned, last_qsto, last_food, last_cgm, prev_cgm, t, meta, cgm, bg, reward, done): once
+        // at most that many operations are outstanding the DMA is complete, and the wave does not sit
+        // through the write burst of its own stores.
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        unstage(a, st, e, basal, bolus, meta);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging area read out before it is refilled
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned ntile = tile + gridDim.x;
+        const bool more = ntile < ntiles;
+        const unsigned next_elem0 = ntile * kBlock + (unsigned)wave * 64u;
+        auto prefetch = [&]() {
+            if (more) stage_tile(a, next_elem0, st);      // in flight while this tile integrates
+        };
+        const uint32_t pid = T1D_META_PID(meta);
+        StepOut<T> o;
+        if (VARIANT == 2) {
+            const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
+            if (__ballot((int)pid != pid0) != 0ull) {
+                atomicOr(a.status, T1D_ST_BAD_LAYOUT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                break;                                   // no stores were issued: the counted wait above would not hold
+            }
+            ParsScalar<T> p;
+            p.load(a.dpar, kMaxPatients, pid0);
+            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
+            write_outputs<MATH>(a, i, e, o);
+            store_env(a, i, pid, e);
+        } else if (VARIANT == 3) {
+            ParsReg<T> p;
+            p.load(lds, (int)pid);                       // 38 ds_reads per tile, then no LDS traffic in the RK4 loop
+            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
+            write_outputs<MATH>(a, i, e, o);
+            store_env(a, i, pid, e);
+        } else {
+            ParsLds<T> p{lds, (int)pid};
+            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
+            write_outputs<MATH>(a, i, e, o);
+            store_env(a, i, pid, e);
+        }
+        if (!more) break;
+        tile = ntile;
+        first = false;
+    }
 }
 
 template <int VARIANT, typename T, typename P>
@@ -496,8 +667,11 @@ struct t1d_ctx {
     double* d_minv64 = nullptr; float* d_minv32 = nullptr;
     int* d_status = nullptr;
     int math = 1;            // RHS arithmetic variant (t1d_ctx_set_option "math")
-    int scalar_params = 1;   // allow the SGPR-parameter kernels for wave-uniform batches
-    int params_mode = 0;     // 0 = LDS re-read per RHS evaluation, 1 = gathered once into VGPRs
+    int scalar_params = 0;   // 1 = wave-uniform batches use the SGPR-parameter kernels
+    int params_mode = -1;    // 0 = LDS re-read per RHS evaluation, 1 = gathered once into VGPRs, -1 = by minutes per launch
+    int pipeline = 0;        // 1 = persistent LDS-DMA pipelined step kernel, 0 = one tile per block
+    int n_cu = 256;
+    int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
 };
 
 static thread_local std::string g_err;
@@ -565,10 +739,12 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
             return fail(T1D_E_NODEVICE, "t1d_ctx_create: no HIP device visible");
         if (hip_device < 0 || hip_device >= ndev) return fail(T1D_E_INVALID, "t1d_ctx_create: bad device index");
         T1D_HIP(hipSetDevice(hip_device));
+        int n_cu = 0;
+        T1D_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, hip_device));
 
         t1d_ctx* c = new (std::nothrow) t1d_ctx();
         if (!c) return fail(T1D_E_INVALID, "t1d_ctx_create: out of host memory");
-        c->device = hip_device; c->np = n_patients; c->S = (int)std::floor(150.0 / st);   // noise_gen.py:41-42
+        c->device = hip_device; c->n_cu = n_cu > 0 ? n_cu : 256; c->np = n_patients; c->S = (int)std::floor(150.0 / st);   // noise_gen.py:41-42
         std::memcpy(c->sensor, sensor_row, sizeof(c->sensor));
         std::memcpy(c->pump, pump_row, sizeof(c->pump));
 
@@ -634,8 +810,18 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         return T1D_OK;
     }
     if (std::strcmp(name, "params_mode") == 0) {
-        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be 0 or 1");
+        if (value < -1 || value > 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be -1, 0 or 1");
         c->params_mode = (int)value;
+        return T1D_OK;
+    }
+    if (std::strcmp(name, "pipe_blocks") == 0) {
+        if (value < 0 || value > 65535) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipe_blocks out of range");
+        c->pipe_blocks = (int)value;
+        return T1D_OK;
+    }
+    if (std::strcmp(name, "pipeline") == 0) {
+        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipeline must be 0 or 1");
+        c->pipeline = (int)value;
         return T1D_OK;
     }
     if (std::strcmp(name, "scalar_params") == 0) {
@@ -727,14 +913,38 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_step: minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_step: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (c->params_mode ? 3 : 1));
+    // measured at 1 Mi envs: the LDS-parameter kernel has the smaller per-launch cost (51 vs 97 us), the
+    // VGPR-parameter kernel the smaller per-minute cost (79 vs 93 us): cross-over at ~3 minutes per launch
+    const int pmode = c->params_mode >= 0 ? c->params_mode : (minutes > 3 ? 1 : 0);
+    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1));
 #define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
+#define T1D_LAUNCH_PIPE(V, TT) hipLaunchKernelGGL((step_pipe_kernel<V, TT>), pgrid, dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
+    const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
+    const char* xb = (const char*)b->x;
+    const size_t rowb = (size_t)b->n * esz;
+    const bool packed = (const char*)b->planned == xb + 13 * rowb && (const char*)b->last_qsto == xb + 14 * rowb &&
+                        (const char*)b->last_food == xb + 15 * rowb && (const char*)b->last_cgm == xb + 16 * rowb &&
+                        (const char*)b->prev_cgm == xb + 17 * rowb && (const char*)b->pts == xb + 18 * rowb &&
+                        b->next_meal && (const char*)b->meta == (const char*)b->t + (size_t)b->n * 4 &&
+                        (const char*)b->next_meal == (const char*)b->t + (size_t)b->n * 8 &&
+                        (size_t)kPackedRows * rowb < ((size_t)1 << 32);
+    if (c->pipeline && (variant >= 1 && variant <= 3) && packed && b->n % kBlock == 0) {
+        // persistent grid: as many blocks as stay resident at T1D_WAVES waves per SIMD (4 SIMDs x waves / 4 waves per block)
+        const unsigned resident = c->pipe_blocks > 0 ? (unsigned)c->pipe_blocks : (unsigned)c->n_cu * T1D_WAVES;
+        const unsigned ntiles = grid_for(b->n).x;
+        const dim3 pgrid(ntiles < resident ? ntiles : resident);
+        if (b->dtype == T1D_F64) { if (variant == 1) T1D_LAUNCH_PIPE(1, double); else if (variant == 2) T1D_LAUNCH_PIPE(2, double); else T1D_LAUNCH_PIPE(3, double); }
+        else { if (variant == 1) T1D_LAUNCH_PIPE(1, float); else if (variant == 2) T1D_LAUNCH_PIPE(2, float); else T1D_LAUNCH_PIPE(3, float); }
+        T1D_HIP(hipGetLastError());
+        return T1D_OK;
+    }
     if (b->dtype == T1D_F64) {
         if (variant == 0) T1D_LAUNCH_STEP(0, double); else if (variant == 1) T1D_LAUNCH_STEP(1, double); else if (variant == 2) T1D_LAUNCH_STEP(2, double); else T1D_LAUNCH_STEP(3, double);
     } else {
         if (variant == 0) T1D_LAUNCH_STEP(0, float); else if (variant == 1) T1D_LAUNCH_STEP(1, float); else if (variant == 2) T1D_LAUNCH_STEP(2, float); else T1D_LAUNCH_STEP(3, float);
     }
 #undef T1D_LAUNCH_STEP
+#undef T1D_LAUNCH_PIPE
     T1D_HIP(hipGetLastError());
     return T1D_OK;
 }
@@ -761,7 +971,8 @@ extern "C" int t1d_rollout_pid(t1d_ctx* c, const t1d_batch* b, const t1d_pid* pi
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_rollout_pid: minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (c->params_mode ? 3 : 1));
+    const int pmode = c->params_mode >= 0 ? c->params_mode : ((int64_t)n_steps * minutes > 3 ? 1 : 0);
+    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1));
 #define T1D_LAUNCH_ROLL(V, TT) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, \
                                                   make_args<TT>(c, b, minutes, n_sub), make_pid<TT>(pid, n_steps))
     if (b->dtype == T1D_F64) {

@@ -43,12 +43,23 @@ template <typename T> struct ParsLds {
     int pid;
     __device__ __forceinline__ T operator()(int idx) const { return base[idx * kMaxPatients + pid]; }
     __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(pid)); }
+    __device__ __forceinline__ void pin() {}
 };
+// the parameters the fast-math RHS reads (everything else is per-minute set-up)
+__device__ constexpr int kRhsPars[] = {DP_KMAX, DP_DK, DP_KABS, DP_RATC, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2,
+                                       DP_K1, DP_K2, DP_VM0, DP_VMX, DP_KM0, DP_M24, DP_M1, DP_KA1, DP_KA2, DP_IVI, DP_P2U,
+                                       DP_IB, DP_KI, DP_M130, DP_M2, DP_KA1KD, DP_KD, DP_KSC};
 // parameters gathered once per lane from the (L2-resident) table and held in VGPRs for the launch
 template <typename T> struct ParsReg {
     T v[DP_COUNT];
     __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
     __device__ __forceinline__ void refresh() {}
+    // make the RHS parameters register-resident HERE (any spill reload happens before this point)
+    __device__ __forceinline__ void pin()
+    {
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(kRhsPars) / sizeof(int)); ++k) asm volatile("" : "+v"(v[kRhsPars[k]]));
+    }
     __device__ __forceinline__ void load(const T* __restrict__ tab, int pid)
     {
 #pragma unroll
@@ -60,6 +71,7 @@ template <typename T> struct ParsScalar {
     T v[DP_COUNT];
     __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
     __device__ __forceinline__ void refresh() {}
+    __device__ __forceinline__ void pin() {}
     __device__ __forceinline__ void load(const T* __restrict__ tab, int np, int pid_uniform)
     {
 #pragma unroll

@@ -238,3 +238,50 @@ def test_full_batch_properties_1m_envs():
     # separately compiled kernel variants may contract FMAs differently: agreement to rounding, not bitwise
     assert float((x_scalar - e2.x).abs().max()) < 1e-9 and float((e.cgm - e2.cgm).abs().max()) < 1e-9
     assert e.sync() == 0 and e2.sync() == 0
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("params", ["lds", "reg", "scalar"])
+def test_pipelined_kernel_matches_tile_kernel_and_oracle(dtype, params):
+    """The persistent LDS-DMA kernel (several tiles per block: grid capped at 3 blocks for 8 tiles) against
+    the one-tile-per-block kernel and the oracle: meals from tables, boluses, 3-min sensor, 40 steps."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    from oracle import t1d_oracle as O
+    n = 2048
+    dt = torch.float64 if dtype == "f64" else torch.float32
+    pid = ((np.arange(n) // 64) % 30) if params == "scalar" else (np.arange(n) % 30)
+    rs = np.random.RandomState(3)
+    z = rs.randn(12, n)
+    lists = [[(int(rs.randint(0, 30)), 40.0), (int(rs.randint(40, 100)), float(rs.randint(10, 80)))] for _ in range(n)]
+    envs = []
+    for pipe in (1, 0):
+        e = _mk(patient=pid, sensor="Dexcom", dtype=dt, noise="host", normals=z, n_sub=4)
+        e.set_option("pipeline", pipe); e.set_option("pipe_blocks", 3)
+        e.set_option("scalar_params", 1 if params == "scalar" else 0)
+        e.set_option("params_mode", 1 if params == "reg" else 0)
+        mt, ma = sb.tables_from_minute_lists(lists, device=e.device, dtype=dt)
+        e.set_meals(mt, ma)
+        e.reset()
+        envs.append(e)
+    orc = O.OracleEnv(pid, sensor="Dexcom", normals=z, integrator="rk4", n_sub=4)
+    orc.reset()
+    dense = np.zeros((120, n))
+    for i, l in enumerate(lists):
+        for m, g in l:
+            dense[m, i] = g
+    b = _basal(pid)
+    tol = 1e-8 if dtype == "f64" else 0.05
+    for k in range(40):
+        a = b * (0.5 + (k % 4) * 0.4)
+        bol = (rs.rand(n) < 0.05) * 0.5
+        for e in envs:
+            e.step(torch.as_tensor(a, dtype=dt, device=e.device), torch.as_tensor(bol, dtype=dt, device=e.device))
+        r = orc.step(a, bol, dense[3 * k:3 * k + 3])
+        for key in ("cgm", "bg", "reward", "meal", "insulin", "x", "planned", "last_cgm", "prev_cgm"):
+            d = float((getattr(envs[0], key).double() - getattr(envs[1], key).double()).abs().max())
+            assert d < (1e-9 if dtype == "f64" else 1e-3), (k, key, d)
+        assert torch.equal(envs[0].t, envs[1].t) and torch.equal(envs[0].meta, envs[1].meta) and torch.equal(envs[0].done, envs[1].done)
+        assert np.abs(envs[0].bg.double().cpu().numpy() - r["bg"]).max() < tol
+        assert np.abs(envs[0].cgm.double().cpu().numpy() - r["cgm"]).max() < tol
+    assert envs[0].sync() == 0 and envs[1].sync() == 0

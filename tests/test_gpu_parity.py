@@ -15,7 +15,7 @@ TOL_ORACLE = 1e-8
 TOL_SCIPY = 1e-3
 
 
-VARIANTS = ("ref", "lds", "scalar")
+VARIANTS = ("ref", "lds", "reg", "scalar", "pipe_lds", "pipe_reg", "pipe_scalar")
 
 
 def _env(variant="scalar", **kw):
@@ -26,7 +26,9 @@ def _env(variant="scalar", **kw):
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     env = BatchedT1DSimEnv(**kw)
     env.set_option("math", 0 if variant == "ref" else 1)
-    env.set_option("scalar_params", 1 if variant == "scalar" else 0)
+    env.set_option("scalar_params", 1 if variant in ("scalar", "pipe_scalar") else 0)
+    env.set_option("pipeline", 1 if variant.startswith("pipe") else 0)
+    env.set_option("params_mode", 1 if variant in ("reg", "pipe_reg") else 0)   # default -1 = chosen by minutes
     return env
 
 
@@ -134,7 +136,7 @@ def test_config2_1024_replicas_vs_scipy(golden, variant):
     assert worst < TOL_SCIPY, worst
 
 
-@pytest.mark.parametrize("variant", ("ref", "lds"))
+@pytest.mark.parametrize("variant", ("ref", "lds", "reg", "pipe_lds", "pipe_reg"))
 def test_all_30_patients_24h_vs_scipy_and_oracle(golden, variant):
     """G2 for every virtual patient in one batch (heterogeneous patient ids in one wave)."""
     import torch
