@@ -81,7 +81,10 @@ enum {
 enum {
     /* every aligned run of 64 consecutive envs simulates ONE patient (same meta patient row):
      * the kernels then keep that patient's parameters in scalar registers. */
-    T1D_BATCH_WAVE_UNIFORM = 1
+    T1D_BATCH_WAVE_UNIFORM = 1,
+    /* skip the InsulinPump quantiser: insulin = basal + bolus exactly as given (drives the patient model
+     * the way T1DPatient.step(Action(CHO, insulin)) does, t1dpatient.py:82) */
+    T1D_BATCH_NO_PUMP = 2
 };
 
 typedef struct t1d_ctx t1d_ctx;

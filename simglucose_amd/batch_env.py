@@ -30,7 +30,8 @@ class BatchedT1DSimEnv:
 
     def __init__(self, patient="adolescent#001", n_envs=None, sensor="Dexcom", pump="Insulet",
                  dtype=torch.float64, device="cuda:0", n_sub=4, seed=0, env_offset=0, noise="philox",
-                 normals=None, random_init_bg=False, extra_outputs=True, sensor_row=None, pump_row=None):
+                 normals=None, random_init_bg=False, extra_outputs=True, sensor_row=None, pump_row=None,
+                 patient_table=None, use_pump=True):
         self._L = _lib.lib()                     # raises T1DError if the HIP extension is missing
         if not torch.cuda.is_available():
             raise _lib.T1DError("BatchedT1DSimEnv needs a ROCm GPU (torch.cuda.is_available() is False)")
@@ -43,6 +44,13 @@ class BatchedT1DSimEnv:
         self.env_offset = int(env_offset)
         self.random_init_bg = bool(random_init_bg)
         self.names, self.table = params.patient_table()
+        if patient_table is not None:            # caller-supplied rows (T1D_P_* column order), e.g. edited parameters
+            self.table = np.ascontiguousarray(np.atleast_2d(np.asarray(patient_table, dtype=np.float64)))
+            if self.table.shape[1] != _lib.P_NCOLS:
+                raise ValueError("patient_table must have %d columns" % _lib.P_NCOLS)
+            self.names = ["custom#%03d" % k for k in range(self.table.shape[0])]
+        if isinstance(patient, str) and patient_table is not None:
+            patient = np.zeros(int(n_envs or 1), dtype=np.int64)
         if isinstance(patient, str):
             if n_envs is None:
                 n_envs = 1
@@ -105,7 +113,7 @@ class BatchedT1DSimEnv:
         pad = (-self.n) % 64
         runs = np.concatenate([pid, np.full(pad, pid[-1])]).reshape(-1, 64)
         self.wave_uniform = bool((runs == runs[:, :1]).all())
-        b.flags = _lib.T1D_BATCH_WAVE_UNIFORM if self.wave_uniform else 0
+        b.flags = (_lib.T1D_BATCH_WAVE_UNIFORM if self.wave_uniform else 0) | (0 if use_pump else _lib.T1D_BATCH_NO_PUMP)
         if noise not in ("philox", "host"):
             raise ValueError("noise must be 'philox' or 'host'")
         self.noise = noise

@@ -36,7 +36,7 @@ template <typename T> struct KArgs {
     const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
     int* status;
     SensorC<T> sen; PumpC<T> pump;
-    int np, S, n_meals, n_normals, minutes, n_sub;
+    int np, S, n_meals, n_normals, minutes, n_sub, flags;
 };
 
 template <typename T> struct PidArgs {
@@ -261,9 +261,14 @@ template <int MATH, typename T, typename P, typename Hook = NoHook>
 __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
                                                 T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook())
 {
-    const T q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
-    T q_bolus = a.pump.min_bolus > T(0) ? a.pump.min_bolus : T(0);     // = pump.bolus(0)
-    if (has_bolus) q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
+    T q_basal, q_bolus;
+    if (a.flags & T1D_BATCH_NO_PUMP) {           // T1DPatient.step driven directly: insulin = basal + bolus as given
+        q_basal = basal; q_bolus = has_bolus ? bolus : T(0);
+    } else {
+        q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
+        q_bolus = a.pump.min_bolus > T(0) ? a.pump.min_bolus : T(0);     // = pump.bolus(0)
+        if (has_bolus) q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
+    }
     const T insulin = q_basal + q_bolus;
     const T div = T(a.minutes), inv_div = T(1) / div;
     StepOut<T> o{T(0), T(0), T(0), T(0)};
@@ -887,7 +892,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.pump.min_bolus = (T)c->pump[0]; a.pump.max_bolus = (T)c->pump[1]; a.pump.inc_bolus = (T)c->pump[2];
     a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
     a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
-    a.minutes = minutes; a.n_sub = n_sub;
+    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags;
     return a;
 }
 

@@ -1,0 +1,129 @@
+"""GPU tests of the drop-in Python surface: the reference's own tests, re-expressed on this package
+(tests/test_sim_engine.py::test_results_consistency, test_seed.py, test_reset.py, test_reward_fun.py,
+test_gym.py of the reference)."""
+import csv
+import os
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _hist(name):
+    with open(os.path.join(GOLDEN, name), newline="") as f:
+        rows = list(csv.DictReader(f))
+    return {k: np.array([float(r[k]) if r[k] else np.nan for r in rows]) for k in rows[0] if k != "Time"}, \
+        [r["Time"] for r in rows]
+
+
+def test_results_consistency_with_upstream_golden_file():
+    """Reference tests/test_sim_engine.py:87-113: adolescent#001, Dexcom(seed 1), Insulet,
+    RandomScenario(2018-01-01 00:00, seed 1), BBController, 2 days == tests/sim_results.csv.
+    The reference asserts rtol 1e-5 (assert_frame_equal); RK4(4) instead of DOPRI5 is inside that."""
+    from simglucose_amd.simulation.env import T1DSimEnv
+    from simglucose_amd.controller.basal_bolus_ctrller import BBController
+    from simglucose_amd.sensor.cgm import CGMSensor
+    from simglucose_amd.actuator.pump import InsulinPump
+    from simglucose_amd.patient.t1dpatient import T1DPatient
+    from simglucose_amd.simulation.scenario_gen import RandomScenario
+    from simglucose_amd.simulation.sim_engine import SimObj, sim
+    start_time = datetime(2018, 1, 1, 0, 0, 0)
+    env = T1DSimEnv(T1DPatient.withName("adolescent#001"), CGMSensor.withName("Dexcom", seed=1),
+                    InsulinPump.withName("Insulet"), RandomScenario(start_time=start_time, seed=1))
+    results = sim(SimObj(env, BBController(), timedelta(days=2), animate=False, path=None))
+    exp, times = _hist("upstream_sim_results.csv")
+    assert len(results) == 961 and list(results.columns) == ["BG", "CGM", "CHO", "insulin", "LBGI", "HBGI", "Risk"]
+    assert str(results.index[1]) == times[1]
+    for col in exp:
+        got = results[col].to_numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(exp[col])), col
+        ok = ~np.isnan(exp[col])
+        assert np.allclose(got[ok], exp[col][ok], rtol=1e-5, atol=1e-8), (col, np.abs(got[ok] - exp[col][ok]).max())
+    assert np.abs(results["BG"].to_numpy() - exp["BG"]).max() < 1e-3          # BASELINE.json's bar
+    assert np.abs(results["CGM"].to_numpy() - exp["CGM"]).max() < 1e-3
+
+
+def test_step_tuple_and_info_keys():
+    from simglucose_amd.simulation.env import T1DSimEnv, Observation
+    from simglucose_amd.controller.base import Action
+    from simglucose_amd.sensor.cgm import CGMSensor
+    from simglucose_amd.actuator.pump import InsulinPump
+    from simglucose_amd.patient.t1dpatient import T1DPatient
+    from simglucose_amd.simulation.scenario import CustomScenario
+    t0 = datetime(2018, 1, 1, 6, 0, 0)
+    env = T1DSimEnv(T1DPatient.withName("adult#001"), CGMSensor.withName("Dexcom", seed=1),
+                    InsulinPump.withName("Insulet"), CustomScenario(t0, [(0.1, 56)]))
+    r = env.reset()
+    assert isinstance(r.observation, Observation) and r.reward == 0 and r.done is False
+    assert set(r.info) == {"sample_time", "patient_name", "meal", "patient_state", "time", "bg", "lbgi", "hbgi", "risk"}
+    assert abs(r.info["bg"] - 138.56) < 1e-9 and r.info["time"] == t0 and r.info["patient_name"] == "adult#001"
+    assert abs(r.observation.CGM - 151.9733141211806) < 1e-9            # known answer
+    s1 = env.step(Action(basal=0.02, bolus=0))
+    s2 = env.step(Action(basal=0.02, bolus=0))
+    s3 = env.step(Action(basal=0.02, bolus=0))                          # minute 6 = 0.1 h: the meal is announced
+    assert s1.info["meal"] == 0 and abs(s3.info["meal"] - 56 / 3.0) < 1e-12
+    assert env.time == t0 + timedelta(minutes=9) and s3.info["patient_state"].shape == (13,)
+    assert env.patient.t == 9 and abs(env.patient.observation.Gsub - s3.info["patient_state"][12] / 1.9152) < 1e-9
+    df = env.show_history()
+    assert len(df) == 4 and np.isnan(df["CHO"].iloc[-1]) and abs(df["insulin"].iloc[0] - 0.02) < 1e-12
+    # custom reward function sees the CGM history window (env.py:100-102)
+    seen = []
+    env.step(Action(basal=0.02, bolus=0), reward_fun=lambda w: seen.append(list(w)) or -len(w))
+    assert seen[0] == env.CGM_hist[-20:] and len(seen[0]) == 5
+
+
+def test_gym_wrapper_seed_reset_semantics():
+    """Reference tests/test_seed.py and tests/test_reset.py."""
+    from simglucose_amd.envs import T1DSimEnv
+    env = T1DSimEnv(patient_name="adult#001")
+    seeds = env.seed(0)
+    assert len(seeds) == 4 and seeds[0] == 0
+    obs0 = env.reset()
+    assert env.env.scenario.start_time == datetime(2018, 1, 1, 23, 0, 0)
+    env.seed(1000)
+    obs1 = env.reset()
+    assert env.env.scenario.start_time == datetime(2018, 1, 1, 14, 0, 0)
+    assert obs0 != obs1
+    # same seed => same sequence of (obs, start time, scenario) across resets; successive resets differ
+    runs = []
+    for _ in range(2):
+        env.seed(7)
+        seq = []
+        for _ in range(3):
+            o = env.reset()
+            seq.append((o.CGM, env.env.scenario.start_time, tuple(env.env.scenario.scenario["meal"]["time"])))
+        runs.append(seq)
+    assert runs[0] == runs[1]
+    assert runs[0][0] != runs[0][1] and runs[0][1] != runs[0][2]
+    assert env.action_space.shape == (1,) and float(env.action_space.high[0]) == 30.0
+    assert env.observation_space.shape == (1,)
+    # 30 gym steps with a scalar basal action; custom reward fun contract (tests/test_reward_fun.py)
+    def reward(window):
+        return 1 if 70 <= window[-1] <= 180 else (-1 if window[-1] > 180 else -2)
+    env2 = T1DSimEnv(patient_name="adolescent#002", reward_fun=reward, seed=3)
+    env2.reset()
+    for _ in range(30):
+        obs, r, done, info = env2.step(np.array([0.015]))
+        assert r == reward([obs.CGM]) and info["sample_time"] == 3.0 and isinstance(done, bool)
+
+
+def test_standalone_patient_steps():
+    """T1DPatient used alone (t1dpatient.py:297-320 style): step(Action(CHO, insulin)) once per minute."""
+    from simglucose_amd.patient.t1dpatient import T1DPatient, Action
+    from oracle import t1d_oracle as O
+    p = T1DPatient.withName("child#005")
+    names, tab = O.patient_table()
+    orc = O.PatientOracle(tab[names.index("child#005")])
+    basal = float(p._params.u2ss * p._params.BW / 6000)
+    for t in range(90):
+        cho = 50.0 if t == 10 else 0.0
+        ins = basal * (3.0 if 10 <= t < 13 else 1.0)
+        p.step(Action(CHO=cho, insulin=ins))
+        orc.step(cho, ins, integrator="rk4", n_sub=4)
+    assert p.t == 90
+    assert np.abs(p.state - orc.x).max() < 1e-7
+    p.reset()
+    assert p.t == 0 and np.array_equal(p.state, tab[names.index("child#005"), :13])
