@@ -131,3 +131,48 @@ def test_standalone_patient_steps():
     assert np.abs(p.state - orc.x).max() < 1e-7
     p.reset()
     assert p.t == 0 and np.array_equal(p.state, tab[names.index("child#005"), :13])
+
+
+def test_batched_gym_env_exact_equals_n_single_wrappers():
+    """BatchedGymT1DSimEnv(exact=True): env i == the single-env gym wrapper seeded with seed + i."""
+    import torch
+    from simglucose_amd.envs import T1DSimEnv, BatchedGymT1DSimEnv
+    n, seed = 3, 11
+    benv = BatchedGymT1DSimEnv(n, patient_name="adult#003", seed=seed, exact=True)
+    singles = []
+    for i in range(n):
+        e = T1DSimEnv(patient_name="adult#003")
+        e.seed(seed + i)
+        singles.append(e)
+    for episode in range(2):
+        ob = benv.reset().cpu().numpy()
+        os_ = [e.reset().CGM for e in singles]
+        assert np.abs(ob - np.array(os_)).max() < 1e-9
+        assert [int(h) for h in benv.start_hour] == [e.env.scenario.start_time.hour for e in singles]
+        for k in range(60):
+            a = 0.01 + 0.002 * (k % 5)
+            obs, rew, done, info = benv.step(torch.full((n,), a, dtype=torch.float64))
+            for i, e in enumerate(singles):
+                o, r, d, inf = e.step(a)
+                assert abs(float(obs[i]) - o.CGM) < 1e-9 and abs(float(rew[i]) - r) < 1e-9 and bool(done[i]) == d
+                assert abs(float(info["meal"][i]) - inf["meal"]) < 1e-12
+
+
+def test_batched_gym_env_device_mode_and_auto_reset():
+    import torch
+    from simglucose_amd.envs import BatchedGymT1DSimEnv
+    n = 4096
+    env = BatchedGymT1DSimEnv(n, patient_name=["child#001", "adult#001"] * (n // 2), seed=3, auto_reset=True)
+    obs = env.reset()
+    assert obs.shape == (n,) and bool((obs >= 39).all()) and int(env.start_hour.min()) >= 0 and int(env.start_hour.max()) <= 23
+    bg0 = env.env.bg.clone()
+    assert 2.3 < float(bg0[1::2].std()) < 3.1          # random_init_bg: sd = sqrt(0.1 x0_13)/Vg = 2.69 mg/dL around 138.56
+    n_done = 0
+    for k in range(200):
+        obs, rew, done, info = env.step(torch.full((n,), 0.05, dtype=torch.float64, device=obs.device))   # heavy basal: hypos
+        n_done += int(done.sum())
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
+    assert n_done > 0                                  # some episodes ended and were re-started in place
+    assert int(env.env.t.min()) < 600 and int(env.env.t.max()) == 600
+    assert int(env.env.episode.max()) >= 2
+    assert env.env.sync() == 0
