@@ -62,8 +62,10 @@ def main():
     ap.add_argument("--n-sub", type=int, default=4)
     ap.add_argument("--sensor", default="Navigator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
     ap.add_argument("--cpu-envs", type=int, default=65536)
-    ap.add_argument("--cpu-steps", type=int, default=60)
+    ap.add_argument("--cpu-steps", type=int, default=600)
     a = ap.parse_args()
 
     import torch
@@ -137,7 +139,7 @@ def main():
                                    % (n, a.sensor, minutes, a.n_sub),
                        "envs_per_gpu": n, "n_sub": a.n_sub, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "step_kernel<%s>" % ("double" if a.dtype == "f64" else "float"),
+                         "traffic": a.traffic_bytes, "kernel": "t1d::step_kernel<1, %s>" % ("double" if a.dtype == "f64" else "float"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
