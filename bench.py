@@ -127,6 +127,15 @@ def main():
     sane = bool(torch.isfinite(bg).all()) and status == 0
 
     if rank == 0:
+        traffic = a.traffic_bytes
+        if traffic is None:                               # last recorded PMC measurement of this exact configuration
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
+                    tj = json.load(f)
+                if (tj["envs"], tj["dtype"], tj["n_sub"], tj["minutes"]) == (n, a.dtype, a.n_sub, minutes):
+                    traffic = tj["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                traffic = None
         algo = ALGO_BYTES[a.dtype] * n * minutes          # algorithmic bytes per launch (per GPU)
         ach = algo / (kern_ms * 1e-3) / 1e9
         out = {
@@ -139,7 +148,7 @@ def main():
                                    % (n, a.sensor, minutes, a.n_sub),
                        "envs_per_gpu": n, "n_sub": a.n_sub, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": a.traffic_bytes, "kernel": "t1d::step_kernel<1, %s>" % ("double" if a.dtype == "f64" else "float"),
+                         "traffic": traffic, "kernel": "t1d::step_kernel<1, %s>" % ("double" if a.dtype == "f64" else "float"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
