@@ -163,8 +163,8 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * Newton-refined reciprocals in the ODE right-hand side; 0 = ocml tanh and IEEE divisions written
  * exactly as t1dpatient.py:138-140,171,178 writes them (A/B and parity reference).
  * "params_mode": where the ODE parameters live during the RK4 loop: 0 = re-read from the LDS table at
- * every use, 1 = gathered once per launch into vector registers, -1 (default) = 0 for launches of up to
- * 3 minutes and 1 for longer ones (the measured cross-over).
+ * every use, 1 = gathered once per launch into vector registers (RK4 stages then run sub-system by
+ * sub-system), 2 = LDS table with a per-minute register copy, -1 (default) = 1.
  * "scalar_params": 1 = batches flagged T1D_BATCH_WAVE_UNIFORM keep the patient row in scalar registers
  * (default 0: measured no faster than the VGPR form).
  * "pipeline": 1 = t1d_step runs the persistent kernel that streams the next tile of envs into LDS with

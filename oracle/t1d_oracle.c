@@ -105,6 +105,60 @@ void t1d_o_rk4_minute(const double* p, double* x, double cho, double ins, double
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Multirate RK4 over one minute (integrator 2): the gastro-intestinal tract (x0, x1, x2) -- the only part
+ * of the model with fast dynamics (kabs up to 1.23/min) and the tanh gastric-emptying term -- is an
+ * autonomous sub-system and is integrated with classical RK4 at ng sub-steps per minute; the ten
+ * glucose/insulin states, whose rates are all <= ~0.45/min, follow with classical RK4 at ns sub-steps,
+ * reading the gut content x2 (rate of appearance, t1dpatient.py:151) from the fine solution at their
+ * stage times t, t+H/2, t+H (ng must be a multiple of 2 ns).  Same RHS arithmetic as t1d_o_rhs.
+ * ---------------------------------------------------------------------------------------- */
+static void o_rhs_gut(const double* p, const double* g, double cho, double lq, double lf, double* dg)
+{
+    double x[13] = {0}, dx[13];
+    x[0] = g[0]; x[1] = g[1]; x[2] = g[2];
+    t1d_o_rhs(p, x, cho, 0.0, lq, lf, dx);
+    dg[0] = dx[0]; dg[1] = dx[1]; dg[2] = dx[2];
+}
+
+void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int ng, int ns)
+{
+    double x2s[257];                     /* x2 on the fine grid, ng <= 256 */
+    double g[3] = {x[0], x[1], x[2]};
+    const double h = 1.0 / (double)ng;
+    x2s[0] = g[2];
+    for (int s = 0; s < ng; ++s) {
+        double k1[3], k2[3], k3[3], k4[3], y[3];
+        o_rhs_gut(p, g, cho, lq, lf, k1);
+        for (int i = 0; i < 3; ++i) y[i] = g[i] + 0.5 * h * k1[i];
+        o_rhs_gut(p, y, cho, lq, lf, k2);
+        for (int i = 0; i < 3; ++i) y[i] = g[i] + 0.5 * h * k2[i];
+        o_rhs_gut(p, y, cho, lq, lf, k3);
+        for (int i = 0; i < 3; ++i) y[i] = g[i] + h * k3[i];
+        o_rhs_gut(p, y, cho, lq, lf, k4);
+        for (int i = 0; i < 3; ++i) g[i] = g[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        x2s[s + 1] = g[2];
+    }
+    const double H = 1.0 / (double)ns;
+    const int stride = ng / ns;          /* fine steps per slow step (even) */
+    for (int s = 0; s < ns; ++s) {
+        double k1[13], k2[13], k3[13], k4[13], y[13];
+        const double xa = x2s[s * stride], xm = x2s[s * stride + stride / 2], xb = x2s[(s + 1) * stride];
+        x[2] = xa;
+        t1d_o_rhs(p, x, cho, ins, lq, lf, k1);
+        for (int i = 3; i < 13; ++i) y[i] = x[i] + 0.5 * H * k1[i];
+        y[0] = x[0]; y[1] = x[1]; y[2] = xm;
+        t1d_o_rhs(p, y, cho, ins, lq, lf, k2);
+        for (int i = 3; i < 13; ++i) y[i] = x[i] + 0.5 * H * k2[i];
+        t1d_o_rhs(p, y, cho, ins, lq, lf, k3);
+        for (int i = 3; i < 13; ++i) y[i] = x[i] + H * k3[i];
+        y[2] = xb;
+        t1d_o_rhs(p, y, cho, ins, lq, lf, k4);
+        for (int i = 3; i < 13; ++i) x[i] = x[i] + H / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    x[0] = g[0]; x[1] = g[1]; x[2] = g[2];
+}
+
+/* ------------------------------------------------------------------------------------------
  * P2: scipy.integrate.ode(...).set_integrator('dopri5').integrate(t+1)
  *     (patient/t1dpatient.py:276-277 construction, :110-113 one call per minute).
  * Hairer's DOPRI5 driver is re-entered for every minute on [t, t+1]; scipy passes the same
@@ -359,6 +413,8 @@ int t1d_o_step(t1d_o_batch* b, const double* basal, const double* bolus, const d
             b->was_eating[i] = (to_eat > 0.0);
             if (integrator == 0) {
                 t1d_o_rk4_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub);
+            } else if (integrator == 2) {
+                t1d_o_mr_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub / 1000, n_sub % 1000);
             } else {
                 if (t1d_o_dopri5_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i],
                                         &b->h_carry[i], dopri_beta, (double)b->t[i]) < 0) rc = -1;
@@ -406,5 +462,6 @@ int t1d_o_patient_minute(const double* p, double* x, double* planned, double* la
     *last_food += to_eat;
     *was_eating = (to_eat > 0.0);
     if (integrator == 0) { t1d_o_rk4_minute(p, x, to_eat, insulin, *last_qsto, *last_food, n_sub); return 4 * n_sub; }
+    if (integrator == 2) { t1d_o_mr_minute(p, x, to_eat, insulin, *last_qsto, *last_food, n_sub / 1000, n_sub % 1000); return 4 * (n_sub / 1000); }
     return t1d_o_dopri5_minute(p, x, to_eat, insulin, *last_qsto, *last_food, h_carry, dopri_beta, (double)t);
 }

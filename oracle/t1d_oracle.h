@@ -56,6 +56,7 @@ typedef struct {
 
 void t1d_o_rhs(const double* p, const double* x, double cho, double ins, double lq, double lf, double* dx);
 void t1d_o_rk4_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int n_sub);
+void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int ng, int ns);
 int t1d_o_dopri5_minute(const double* p, double* y, double cho, double ins, double lq, double lf,
                         double* h_carry, double beta, double t_start);
 double t1d_o_pump(double amount, double inc, double lo, double hi);

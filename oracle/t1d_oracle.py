@@ -159,6 +159,8 @@ def risk(bg):
 
 
 DOPRI_BETA = 0.04     # what the Fortran driver uses when scipy hands it beta = 0.0
+# integrator codes of t1d_oracle.c; "mr" = multirate RK4 with n_sub = ng * 1000 + ns
+_INTEG = {"rk4": 0, "dopri": 1, "mr": 2}
 
 
 class PatientOracle:
@@ -174,7 +176,7 @@ class PatientOracle:
     def step(self, meal, insulin, integrator="rk4", n_sub=4, beta=DOPRI_BETA):
         r = lib().t1d_o_patient_minute(_p(self.p), _p(self.x), C.byref(self.planned), C.byref(self.lq),
                                        C.byref(self.lf), C.byref(self.eat), C.byref(self.h), self.t,
-                                       float(meal), float(insulin), 0 if integrator == "rk4" else 1,
+                                       float(meal), float(insulin), _INTEG[integrator],
                                        int(n_sub), float(beta))
         if r < 0:
             raise RuntimeError("oracle DOPRI5 failed")
@@ -241,7 +243,7 @@ class OracleEnv:
         if cho is not None:
             cho = np.ascontiguousarray(cho, dtype=np.float64); assert cho.shape == (int(self.sample_time), n)
             cp = _p(cho)
-        rc = lib().t1d_o_step(C.byref(self._b), _p(basal), bp, cp, 0 if self.integrator == "rk4" else 1,
+        rc = lib().t1d_o_step(C.byref(self._b), _p(basal), bp, cp, _INTEG[self.integrator],
                               int(self.n_sub), float(self.beta), C.byref(self._o))
         if rc != 0:
             raise RuntimeError("oracle DOPRI5 failed")

@@ -257,7 +257,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `pre_rk4` runs once, immediately before the first minute's RK4 sub-steps: from there to the end of
 // the integration the wave issues no vector-memory instruction, which is where the persistent kernel
 // starts the LDS-DMA of its next tile.
-template <int MATH, typename T, typename P, typename Hook = NoHook>
+template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false>
 __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
                                                 T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook())
 {
@@ -288,7 +288,7 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
         }
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
         if (m == 0) pre_rk4();
-        rk4_minute<MATH>(p, u, e.x, a.n_sub);
+        rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP);
         e.t += 1;
         const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
         const T cgm = measure_apply(a, e, gsub, noise, due);                      // env.py:62
@@ -324,14 +324,15 @@ __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env
 //         1: fast arithmetic, parameters re-read from LDS per RHS evaluation (any patient layout)
 //         2: fast arithmetic, wave-uniform patient, parameters in SGPRs (T1D_BATCH_WAVE_UNIFORM)
 //         3: fast arithmetic, parameters gathered once per lane into VGPRs (any patient layout)
+//         4: fast arithmetic, LDS table, RHS parameters copied into VGPRs for each minute's sub-step loop only
 template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
 
 template <int VARIANT, typename T>
 __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> a)
 {
     constexpr int MATH = VariantMath<VARIANT>::value;
-    __shared__ T lds[VARIANT >= 2 ? 1 : DP_COUNT * kMaxPatients];
-    if (VARIANT < 2) stage_pars(a, lds);
+    __shared__ T lds[(VARIANT == 2 || VARIANT == 3) ? 1 : DP_COUNT * kMaxPatients];
+    if (VARIANT < 2 || VARIANT == 4) stage_pars(a, lds);
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
     if ((int64_t)i >= a.n) return;
@@ -342,7 +343,10 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     const T basal = at(a.basal, i);
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
     StepOut<T> o;
-    if (VARIANT == 2) {
+    if (VARIANT == 4) {
+        ParsLds<T> p{lds, (int)pid};
+        o = step_body<MATH, T, ParsLds<T>, NoHook, true>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+    } else if (VARIANT == 2) {
         const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
         if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
         ParsScalar<T> p;
@@ -815,7 +819,7 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         return T1D_OK;
     }
     if (std::strcmp(name, "params_mode") == 0) {
-        if (value < -1 || value > 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be -1, 0 or 1");
+        if (value < -1 || value > 2) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be -1, 0, 1 or 2");
         c->params_mode = (int)value;
         return T1D_OK;
     }
@@ -918,10 +922,10 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_step: minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_step: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    // measured at 1 Mi envs: the LDS-parameter kernel has the smaller per-launch cost (51 vs 97 us), the
-    // VGPR-parameter kernel the smaller per-minute cost (79 vs 93 us): cross-over at ~3 minutes per launch
-    const int pmode = c->params_mode >= 0 ? c->params_mode : (minutes > 3 ? 1 : 0);
-    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1));
+    // measured at 1 Mi envs, fp64: VGPR parameters + sub-system-wise RK4 cost ~75 us + 78 us/minute, the LDS-
+    // parameter kernel ~55 us + 93 us/minute: equal at one minute per launch, VGPR form ahead beyond
+    const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
+    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode == 2 ? 4 : (pmode ? 3 : 1)));
 #define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
 #define T1D_LAUNCH_PIPE(V, TT) hipLaunchKernelGGL((step_pipe_kernel<V, TT>), pgrid, dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
     const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
@@ -944,9 +948,9 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         return T1D_OK;
     }
     if (b->dtype == T1D_F64) {
-        if (variant == 0) T1D_LAUNCH_STEP(0, double); else if (variant == 1) T1D_LAUNCH_STEP(1, double); else if (variant == 2) T1D_LAUNCH_STEP(2, double); else T1D_LAUNCH_STEP(3, double);
+        if (variant == 0) T1D_LAUNCH_STEP(0, double); else if (variant == 1) T1D_LAUNCH_STEP(1, double); else if (variant == 2) T1D_LAUNCH_STEP(2, double); else if (variant == 3) T1D_LAUNCH_STEP(3, double); else T1D_LAUNCH_STEP(4, double);
     } else {
-        if (variant == 0) T1D_LAUNCH_STEP(0, float); else if (variant == 1) T1D_LAUNCH_STEP(1, float); else if (variant == 2) T1D_LAUNCH_STEP(2, float); else T1D_LAUNCH_STEP(3, float);
+        if (variant == 0) T1D_LAUNCH_STEP(0, float); else if (variant == 1) T1D_LAUNCH_STEP(1, float); else if (variant == 2) T1D_LAUNCH_STEP(2, float); else if (variant == 3) T1D_LAUNCH_STEP(3, float); else T1D_LAUNCH_STEP(4, float);
     }
 #undef T1D_LAUNCH_STEP
 #undef T1D_LAUNCH_PIPE
@@ -976,7 +980,7 @@ extern "C" int t1d_rollout_pid(t1d_ctx* c, const t1d_batch* b, const t1d_pid* pi
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_rollout_pid: minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    const int pmode = c->params_mode >= 0 ? c->params_mode : ((int64_t)n_steps * minutes > 3 ? 1 : 0);
+    const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
     const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1));
 #define T1D_LAUNCH_ROLL(V, TT) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, \
                                                   make_args<TT>(c, b, minutes, n_sub), make_pid<TT>(pid, n_steps))

@@ -39,6 +39,7 @@ constexpr int kBlock = 256;
 // parameters re-read from LDS at every use; refresh() makes the base opaque so the compiler
 // cannot hoist the reads out of an RHS evaluation and pin them in VGPRs
 template <typename T> struct ParsLds {
+    static constexpr bool kSplitRk4 = false;   // measured (1 Mi envs, fp64): 93 us/minute unsplit vs 98 split
     const T* base;     // the __shared__ table, [DP_COUNT][kMaxPatients]: one ds_read with an immediate offset per use
     int pid;
     __device__ __forceinline__ T operator()(int idx) const { return base[idx * kMaxPatients + pid]; }
@@ -51,6 +52,7 @@ __device__ constexpr int kRhsPars[] = {DP_KMAX, DP_DK, DP_KABS, DP_RATC, DP_KP1,
                                        DP_IB, DP_KI, DP_M130, DP_M2, DP_KA1KD, DP_KD, DP_KSC};
 // parameters gathered once per lane from the (L2-resident) table and held in VGPRs for the launch
 template <typename T> struct ParsReg {
+    static constexpr bool kSplitRk4 = true;    // measured: 75 us/minute split vs 79 unsplit, and far fewer spills around the loop
     T v[DP_COUNT];
     __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
     __device__ __forceinline__ void refresh() {}
@@ -68,6 +70,7 @@ template <typename T> struct ParsReg {
 };
 // parameters of a wave-uniform patient, fetched once with scalar loads (SGPR resident)
 template <typename T> struct ParsScalar {
+    static constexpr bool kSplitRk4 = true;
     T v[DP_COUNT];
     __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
     __device__ __forceinline__ void refresh() {}
@@ -222,9 +225,141 @@ __device__ __forceinline__ void rhs(P& p, const MinuteIn<T>& u, const T (&x)[13]
     k[12] = (x[12] >= T(0)) ? d12 : T(0);                                      // :202
 }
 
-// One minute of classical RK4 in n_sub sub-steps; replaces scipy's DOPRI5 (t1dpatient.py:110-113).
+// ---- the same RHS in two independent pieces -----------------------------------------------------
+// The insulin sub-system (x5..x11) does not depend on the other six states, and those six need only the
+// stage values of x6 (insulin action) and x8 (delayed insulin) from it.  Evaluating the classical RK4
+// stages sub-system by sub-system is therefore the SAME arithmetic as evaluating the 13-state RHS four
+// times -- every k[i] is formed from the same operands -- but only one sub-system's stage vectors are
+// alive at a time: 7 (then 6) x {stage input, accumulator, slope} instead of 13 x 3, which is what
+// decides the occupancy of this fp64 kernel.
+// xi = (x5, x6, x7, x8, x9, x10, x11)
+template <typename T, typename P>
+__device__ __forceinline__ void rhs_insulin(P& p, T ins, const T (&xi)[7], T (&k)[7])
+{
+    p.refresh();
+    const T x5 = xi[0], x6 = xi[1], x7 = xi[2], x8 = xi[3], x9 = xi[4], x10 = xi[5], x11 = xi[6];
+    const T d5 = -p(DP_M24) * x5 + p(DP_M1) * x9 + p(DP_KA1) * x10 + p(DP_KA2) * x11;          // :176
+    const T it = x5 * p(DP_IVI);                                                               // :178
+    k[0] = (x5 >= T(0)) ? d5 : T(0);                                                           // :179
+    const T p2u = p(DP_P2U);
+    k[1] = -p2u * x6 + p2u * (it - p(DP_IB));                                                  // :182
+    const T ki = p(DP_KI);
+    k[2] = -ki * (x7 - it);                                                                    // :185
+    k[3] = -ki * (x8 - x7);                                                                    // :187
+    const T d9 = -p(DP_M130) * x9 + p(DP_M2) * x5;                                             // :190
+    k[4] = (x9 >= T(0)) ? d9 : T(0);                                                           // :191
+    const T d10 = ins - p(DP_KA1KD) * x10;                                                     // :194
+    k[5] = (x10 >= T(0)) ? d10 : T(0);                                                         // :195
+    const T d11 = p(DP_KD) * x10 - p(DP_KA2) * x11;                                            // :197
+    k[6] = (x11 >= T(0)) ? d11 : T(0);                                                         // :198
+}
+// xg = (x0, x1, x2, x3, x4, x12); x6, x8 = the insulin sub-system's values at this stage
+template <typename T, typename P>
+__device__ __forceinline__ void rhs_glucose(P& p, const MinuteIn<T>& u, const T (&xg)[6], T x6, T x8, T (&k)[6])
+{
+    p.refresh();
+    const T x0 = xg[0], x1 = xg[1], x2 = xg[2], x3 = xg[3], x4 = xg[4], x12 = xg[5];
+    const T qsto = x0 + x1;                                                                    // :126
+    const T kmax = p(DP_KMAX);
+    k[0] = -kmax * x0 + u.d_mg;                                                                // :133
+    const T hi = sizeof(T) == 8 ? T(350) : T(40), lo = sizeof(T) == 8 ? T(-745) : T(-80);
+    const T a2 = t_max(t_min(u.aa * (qsto - u.bD), hi), lo);
+    const T c2 = t_max(t_min(u.cc * (qsto - u.dD), hi), lo);
+    const T ea = exp_core(a2), ec = exp_core(c2);
+    const T kgut = kmax + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));                 // :135-142
+    k[1] = kmax * x0 - x1 * kgut;                                                              // :145
+    k[2] = kgut * x1 - p(DP_KABS) * x2;                                                        // :148
+    const T rat = p(DP_RATC) * x2;                                                             // :151
+    const T egp = p(DP_KP1) - p(DP_KP2) * x3 - p(DP_KP3) * x8;                                 // :153
+    const T et = p(DP_KE1) * t_max(x3 - p(DP_KE2), T(0));                                      // :158-161
+    const T k1x3 = p(DP_K1) * x3, k2x4 = p(DP_K2) * x4;
+    const T d3 = t_max(egp, T(0)) + rat - p(DP_FSNC) - et - k1x3 + k2x4;                       // :165
+    k[3] = (x3 >= T(0)) ? d3 : T(0);                                                           // :167
+    const T vmt = p(DP_VM0) + p(DP_VMX) * x6;                                                  // :169
+    const T uid = fdiv(vmt * x4, p(DP_KM0) + x4);                                              // :171
+    const T d4 = -uid + k1x3 - k2x4;                                                           // :172
+    k[4] = (x4 >= T(0)) ? d4 : T(0);                                                           // :173
+    const T ksc = p(DP_KSC);
+    const T d12 = -ksc * x12 + ksc * x3;                                                       // :201
+    k[5] = (x12 >= T(0)) ? d12 : T(0);                                                         // :202
+}
+
+// Classical RK4 sub-steps, insulin sub-system first, then the other six states with its stage values.
+template <typename T, typename P>
+__device__ __forceinline__ void rk4_substeps_split(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub)
+{
+    const T h = T(1) / T(n_sub);
+    const T hh = T(0.5) * h, h6 = h / T(6);
+    for (int s = 0; s < n_sub; ++s) {
+        T s6[4], s8[4];                      // x6, x8 as the four stages see them
+        {
+            T xi[7], y[7], acc[7], k[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) xi[i] = x[5 + i];
+            s6[0] = xi[1]; s8[0] = xi[3];
+            rhs_insulin(p, u.ins, xi, k);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { acc[i] = k[i]; y[i] = xi[i] + hh * k[i]; }
+            s6[1] = y[1]; s8[1] = y[3];
+            rhs_insulin(p, u.ins, y, k);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { acc[i] += T(2) * k[i]; y[i] = xi[i] + hh * k[i]; }
+            s6[2] = y[1]; s8[2] = y[3];
+            rhs_insulin(p, u.ins, y, k);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { acc[i] += T(2) * k[i]; y[i] = xi[i] + h * k[i]; }
+            s6[3] = y[1]; s8[3] = y[3];
+            rhs_insulin(p, u.ins, y, k);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[5 + i] = xi[i] + h6 * (acc[i] + k[i]);
+        }
+        // keep the two passes apart: interleaving them for ILP would bring the register pressure back
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            T xg[6], y[6], acc[6], k[6];
+            xg[0] = x[0]; xg[1] = x[1]; xg[2] = x[2]; xg[3] = x[3]; xg[4] = x[4]; xg[5] = x[12];
+            rhs_glucose(p, u, xg, s6[0], s8[0], k);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { acc[i] = k[i]; y[i] = xg[i] + hh * k[i]; }
+            rhs_glucose(p, u, y, s6[1], s8[1], k);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { acc[i] += T(2) * k[i]; y[i] = xg[i] + hh * k[i]; }
+            rhs_glucose(p, u, y, s6[2], s8[2], k);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { acc[i] += T(2) * k[i]; y[i] = xg[i] + h * k[i]; }
+            rhs_glucose(p, u, y, s6[3], s8[3], k);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xg[i] = xg[i] + h6 * (acc[i] + k[i]);
+            x[0] = xg[0]; x[1] = xg[1]; x[2] = xg[2]; x[3] = xg[3]; x[4] = xg[4]; x[12] = xg[5];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int MATH, typename T, typename P>
-__device__ __forceinline__ void rk4_minute(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub)
+__device__ __forceinline__ void rk4_substeps(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub);
+
+// One minute of classical RK4 in n_sub sub-steps; replaces scipy's DOPRI5 (t1dpatient.py:110-113).
+// LOCAL: the RHS parameters are copied from the LDS table into VGPRs for the duration of the sub-step
+// loop only (28 ds_reads and one wait per minute): no LDS latency inside the loop, and no register is
+// held by a parameter outside it.
+template <int MATH, typename T, typename P>
+__device__ __forceinline__ void rk4_minute(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub, bool local_copy = false)
+{
+    if (MATH == 1 && local_copy) {
+        ParsReg<T> q;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(kRhsPars) / sizeof(int)); ++k) q.v[kRhsPars[k]] = p(kRhsPars[k]);
+        rk4_substeps<MATH>(q, u, x, n_sub);
+    } else if (MATH == 1 && P::kSplitRk4) {
+        rk4_substeps_split(p, u, x, n_sub);
+    } else {
+        rk4_substeps<MATH>(p, u, x, n_sub);
+    }
+}
+
+template <int MATH, typename T, typename P>
+__device__ __forceinline__ void rk4_substeps(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub)
 {
     const T h = T(1) / T(n_sub);
     const T hh = T(0.5) * h, h6 = h / T(6);

@@ -46,7 +46,7 @@ def main():
     cfgs = []
     for layout in ("mod30", "run64"):
         env, pool = make(a.envs, layout, dt, a.sensor, a.n_sub)
-        for var in ("ref", "lds", "reg", "scalar", "pipe_lds", "pipe_reg", "pipe_scalar"):
+        for var in ("lds", "reg", "loc", "pipe_lds"):
             if var in ("scalar", "pipe_scalar") and not env.wave_uniform:
                 continue
             cfgs.append((layout, var, env, pool))
@@ -55,7 +55,7 @@ def main():
         for layout, var, env, pool in cfgs:
             env.set_option("math", 0 if var == "ref" else 1)
             env.set_option("scalar_params", 1 if var in ("scalar", "pipe_scalar") else 0)
-            env.set_option("params_mode", 1 if var in ("reg", "pipe_reg") else 0)
+            env.set_option("params_mode", 1 if var in ("reg", "pipe_reg") else (2 if var == "loc" else 0))
             env.set_option("pipeline", 1 if var.startswith("pipe") else 0)
             for k in range(3):
                 env.step(pool[k % 4])
