@@ -36,7 +36,7 @@ template <typename T> struct KArgs {
     const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
     int* status;
     SensorC<T> sen; PumpC<T> pump;
-    int np, S, n_meals, n_normals, minutes, n_sub, flags;
+    int np, S, n_meals, n_normals, minutes, n_sub, flags, stagger;
 };
 
 template <typename T> struct PidArgs {
@@ -463,6 +463,12 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_pipe_kernel(const KArg
     if (tile >= ntiles) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     Stage<T>* st = &stage[wave];
+    // Identical waves that start together stay in lock-step: both waves of a SIMD are in their latency-bound
+    // prologue/epilogue at the same time and in the VALU-dense RK4 loop at the same time.  Delaying the
+    // second half of the grid (the second workgroup of each CU under round-robin dispatch) by a fraction
+    // of a tile puts the pairs out of phase for the rest of the launch.
+    if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2)
+        for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
     stage_tile(a, tile * kBlock + (unsigned)wave * 64u, st);
     bool first = true;
     for (;;) {
@@ -681,6 +687,7 @@ struct t1d_ctx {
     int pipeline = 0;        // 1 = persistent LDS-DMA pipelined step kernel, 0 = one tile per block
     int n_cu = 256;
     int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
+    int pipe_stagger = 0;    // s_sleep(127) iterations (~3.4 us each) by which the second half of the persistent grid starts late
 };
 
 static thread_local std::string g_err;
@@ -823,6 +830,11 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         c->params_mode = (int)value;
         return T1D_OK;
     }
+    if (std::strcmp(name, "pipe_stagger") == 0) {
+        if (value < 0 || value > 64) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipe_stagger out of range");
+        c->pipe_stagger = (int)value;
+        return T1D_OK;
+    }
     if (std::strcmp(name, "pipe_blocks") == 0) {
         if (value < 0 || value > 65535) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipe_blocks out of range");
         c->pipe_blocks = (int)value;
@@ -896,7 +908,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.pump.min_bolus = (T)c->pump[0]; a.pump.max_bolus = (T)c->pump[1]; a.pump.inc_bolus = (T)c->pump[2];
     a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
     a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
-    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags;
+    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags; a.stagger = c->pipe_stagger;
     return a;
 }
 

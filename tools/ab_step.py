@@ -46,7 +46,7 @@ def main():
     cfgs = []
     for layout in ("mod30", "run64"):
         env, pool = make(a.envs, layout, dt, a.sensor, a.n_sub)
-        for var in ("lds", "reg", "loc", "pipe_lds"):
+        for var in ("lds", "reg", "pipe_lds", "pipe_reg"):
             if var in ("scalar", "pipe_scalar") and not env.wave_uniform:
                 continue
             cfgs.append((layout, var, env, pool))
