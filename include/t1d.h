@@ -84,7 +84,10 @@ enum {
     T1D_BATCH_WAVE_UNIFORM = 1,
     /* skip the InsulinPump quantiser: insulin = basal + bolus exactly as given (drives the patient model
      * the way T1DPatient.step(Action(CHO, insulin)) does, t1dpatient.py:82) */
-    T1D_BATCH_NO_PUMP = 2
+    T1D_BATCH_NO_PUMP = 2,
+    /* the caller vouches that no env starts a new 150-minute CGM-noise block during this t1d_step call
+     * (e.g. all envs were reset together and the host tracks the clock): skips the refill pre-kernel */
+    T1D_BATCH_NO_REFILL_DUE = 4
 };
 
 typedef struct t1d_ctx t1d_ctx;
@@ -164,7 +167,10 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * exactly as t1dpatient.py:138-140,171,178 writes them (A/B and parity reference).
  * "params_mode": where the ODE parameters live during the RK4 loop: 0 = re-read from the LDS table at
  * every use, 1 = gathered once per launch into vector registers (RK4 stages then run sub-system by
- * sub-system), 2 = LDS table with a per-minute register copy, -1 (default) = 1.
+ * sub-system), -1 (default) = 1.
+ * "split_refill": 1 (default) = when a launch takes at most one CGM sample (minutes <= sample_time) the
+ * rarely needed rebuild of the 150-minute noise block runs as its own small kernel ahead of a step kernel
+ * compiled without it (its registers would otherwise cost the step kernel ~20 %); 0 = always inline.
  * "scalar_params": 1 = batches flagged T1D_BATCH_WAVE_UNIFORM keep the patient row in scalar registers
  * (default 0: measured no faster than the VGPR form).
  * "pipeline": 1 = t1d_step runs the persistent kernel that streams the next tile of envs into LDS with

@@ -14,6 +14,7 @@ T1D_F64, T1D_F32 = 0, 1
 T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE, T1D_ST_BAD_LAYOUT = 1, 2, 4
 T1D_BATCH_WAVE_UNIFORM = 1
 T1D_BATCH_NO_PUMP = 2
+T1D_BATCH_NO_REFILL_DUE = 4
 P_NCOLS = 45
 MEAL_UNUSED = 0x7FFFFFFF
 META_EATING = 0x100

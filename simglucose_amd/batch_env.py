@@ -122,6 +122,8 @@ class BatchedT1DSimEnv:
                 raise ValueError("noise='host' needs normals[n_draws, n]")
             self.set_normals(normals)
         self._closed = False
+        self._clock = None         # minutes since the last FULL reset while every env shares one clock, else None
+        self._flags0 = b.flags
 
     # ------------------------------------------------------------------ inputs
     def _as_input(self, v, buf):
@@ -178,6 +180,7 @@ class BatchedT1DSimEnv:
         if mask is not None:
             mask = torch.as_tensor(mask).to(self.device).to(torch.uint8).contiguous()
             mptr = C.c_void_p(mask.data_ptr())
+        self._clock = 0 if mask is None else None
         with torch.cuda.device(self.device):
             _lib.check(self._L.t1d_reset(self._ctx, C.byref(b), mptr, int(self.random_init_bg), self._stream()))
         b.x0_override = None
@@ -202,6 +205,14 @@ class BatchedT1DSimEnv:
             b.cho = cho.data_ptr()
         else:
             b.cho = None
+        b.flags = self._flags0
+        if self._clock is not None:
+            # every env shares the clock: the host knows whether a sample in (t, t + minutes] opens a noise block
+            st, S = self.minutes_per_step, int(150 // self.sample_time)
+            due = any((t1 % st == 0) and ((1 + t1 // st) % S == 0) for t1 in range(self._clock + 1, self._clock + minutes + 1))
+            if not due:
+                b.flags = self._flags0 | _lib.T1D_BATCH_NO_REFILL_DUE
+            self._clock += minutes
         with torch.cuda.device(self.device):
             _lib.check(self._L.t1d_step(self._ctx, C.byref(b), minutes, self.n_sub, self._stream()))
         self._keep = (bas, cho)
@@ -226,6 +237,9 @@ class BatchedT1DSimEnv:
         for k in ("sum_risk", "min_bg", "max_bg", "n_low", "n_high"):
             setattr(p, k, stats[k].data_ptr() if k in stats else None)
         self._b.cho = None
+        self._b.flags = self._flags0
+        if self._clock is not None:
+            self._clock += int(n_steps) * self.minutes_per_step
         with torch.cuda.device(self.device):
             _lib.check(self._L.t1d_rollout_pid(self._ctx, C.byref(self._b), C.byref(p), int(n_steps),
                                                self.minutes_per_step, self.n_sub, self._stream()))
@@ -255,6 +269,7 @@ class BatchedT1DSimEnv:
     def load_state_dict(self, sd):
         for k in _STATE_KEYS + ("cgm",):
             getattr(self, k).copy_(sd[k])
+        self._clock = None
 
     def close(self):
         if not self._closed and self._ctx:

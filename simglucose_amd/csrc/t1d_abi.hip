@@ -176,7 +176,11 @@ __device__ T1D_REFILL_ATTR void noise_refill(T* __restrict__ pts, const T* __res
 
 // next(CGMNoise) for sample index s (noise_gen.py:61-69).  cur = rows 22..25 of pts as loaded with the
 // env state; updated (and stored) when the sample enters a new 15-minute interval.
-template <typename T>
+// REFILL = false: the block has already been rebuilt by refill_kernel (t1d_step launches it ahead of the
+// step kernel), which keeps the rarely-run refill code -- Philox, Box-Muller, ten Johnson transforms, the
+// 11x11 spline operator -- and above all its registers out of the step kernel: with it inlined the fp64
+// step kernel needs 256 VGPRs + scratch, without it 180-220 and no scratch (117 vs 140 us at 1 Mi envs).
+template <bool REFILL, typename T>
 __device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, T (&cur)[4])
 {
     const int64_t n = a.n;
@@ -185,7 +189,7 @@ __device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, 
     const int tau = (j + 1) * st;
     const int m = tau / 15 < 9 ? tau / 15 : 9;
     const int mprev = (tau - st) / 15 < 9 ? (tau - st) / 15 : 9;
-    if (j == 0) {                       // deque empty: build the next 150-minute block
+    if (REFILL && j == 0) {             // deque empty: build the next 150-minute block
         T e = at(a.ar_e, i);            // the AR(1) state is touched by refills only
         noise_refill<T>(a.pts, a.normals, a.minv, a.episode, a.status, n, i, a.env_offset, a.seed, a.n_normals, b, a.sen, &e);
         at(a.ar_e, i) = e;
@@ -204,12 +208,12 @@ __device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, 
 // under the ODE integration: the noise of the sample due at minute t+1 does not depend on the
 // patient state, so it is drawn BEFORE the RK4 sub-steps (sample index = 1 + (t+1)/st: reset used
 // #0 and #1) and added to Gsub after them.
-template <typename T>
+template <bool REFILL, typename T>
 __device__ __forceinline__ T measure_noise(const KArgs<T>& a, unsigned i, Env<T>& e, bool& due)
 {
     const int t1 = e.t + 1;
     due = (t1 % a.sen.st) == 0;
-    return due ? noise_sample(a, i, 1 + t1 / a.sen.st, e.cur) : T(0);
+    return due ? noise_sample<REFILL>(a, i, 1 + t1 / a.sen.st, e.cur) : T(0);
 }
 template <typename T>
 __device__ __forceinline__ T measure_apply(const KArgs<T>& a, Env<T>& e, T gsub, T noise, bool due)
@@ -257,12 +261,12 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `pre_rk4` runs once, immediately before the first minute's RK4 sub-steps: from there to the end of
 // the integration the wave issues no vector-memory instruction, which is where the persistent kernel
 // starts the LDS-DMA of its next tile.
-template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false>
+template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false, bool REFILL = true>
 __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
                                                 T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook())
 {
     T q_basal, q_bolus;
-    if (a.flags & T1D_BATCH_NO_PUMP) {           // T1DPatient.step driven directly: insulin = basal + bolus as given
+    if (a.flags & (T1D_BATCH_NO_PUMP | 0x200)) { // T1DPatient.step driven directly: insulin = basal + bolus as given
         q_basal = basal; q_bolus = has_bolus ? bolus : T(0);
     } else {
         q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
@@ -275,7 +279,7 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
     for (int m = 0; m < a.minutes; ++m) {
         const T meal = a.cho ? at(row(a.cho, a.n, m), i) : meal_lookup(a, i, e);      // env.py:50
         bool due;
-        const T noise = measure_noise(a, i, e, due);
+        const T noise = (a.flags & 0x400) ? (due = false, T(0)) : measure_noise<REFILL>(a, i, e, due);
         MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
         // every load this minute issued is needed by the integration anyway: drain them HERE, on every
         // path, so that the compiler's own wait cannot land behind the hook's (invisible) DMA instructions
@@ -288,7 +292,7 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
         }
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
         if (m == 0) pre_rk4();
-        rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP);
+        if (!(a.flags & 0x800)) rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP);
         e.t += 1;
         const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
         const T cgm = measure_apply(a, e, gsub, noise, due);                      // env.py:62
@@ -299,12 +303,21 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
     return o;
 }
 
+// risk of CGM_hist[-1] (risk_diff, env.py:27-33): independent of this step's integration, so callers
+// evaluate it BEFORE the minute loop, where it overlaps with the pump / meal / noise chains
 template <int MATH, typename T>
-__device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env<T>& e, const StepOut<T>& o)
+__device__ __forceinline__ T prev_risk(const KArgs<T>& a, T prev_cgm)
 {
-    T l, h, r, rp, rc;
-    risk_index1<MATH>(e.prev_cgm, l, h, rp);              // risk_diff, env.py:27-33
-    risk_index1<MATH>(o.cgm, l, h, rc);
+    T l, h, rp = T(0);
+    if (!(a.flags & 0x100)) risk_index1<MATH>(prev_cgm, l, h, rp);
+    return rp;
+}
+
+template <int MATH, typename T>
+__device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env<T>& e, const StepOut<T>& o, T rp)
+{
+    T l, h, r, rc = T(0);
+    if (!(a.flags & 0x100)) risk_index1<MATH>(o.cgm, l, h, rc);
     at(a.reward, i) = rp - rc;
     e.prev_cgm = o.cgm;
     at(a.cgm, i) = o.cgm; at(a.bg, i) = o.bg;
@@ -324,15 +337,14 @@ __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env
 //         1: fast arithmetic, parameters re-read from LDS per RHS evaluation (any patient layout)
 //         2: fast arithmetic, wave-uniform patient, parameters in SGPRs (T1D_BATCH_WAVE_UNIFORM)
 //         3: fast arithmetic, parameters gathered once per lane into VGPRs (any patient layout)
-//         4: fast arithmetic, LDS table, RHS parameters copied into VGPRs for each minute's sub-step loop only
 template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
 
-template <int VARIANT, typename T>
+template <int VARIANT, typename T, bool REFILL = true>
 __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> a)
 {
     constexpr int MATH = VariantMath<VARIANT>::value;
     __shared__ T lds[(VARIANT == 2 || VARIANT == 3) ? 1 : DP_COUNT * kMaxPatients];
-    if (VARIANT < 2 || VARIANT == 4) stage_pars(a, lds);
+    if (VARIANT < 2) stage_pars(a, lds);
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
     if ((int64_t)i >= a.n) return;
@@ -342,25 +354,23 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     load_env(a, i, meta, e);
     const T basal = at(a.basal, i);
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+    const T rp = prev_risk<MATH>(a, e.prev_cgm);
     StepOut<T> o;
-    if (VARIANT == 4) {
-        ParsLds<T> p{lds, (int)pid};
-        o = step_body<MATH, T, ParsLds<T>, NoHook, true>(a, p, i, e, basal, bolus, a.bolus != nullptr);
-    } else if (VARIANT == 2) {
+    if (VARIANT == 2) {
         const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
         if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
         ParsScalar<T> p;
         p.load(a.dpar, kMaxPatients, pid0);
-        o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+        o = step_body<MATH, T, ParsScalar<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
     } else if (VARIANT == 3) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
-        o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
     } else {
         ParsLds<T> p{lds, (int)pid};
-        o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
     }
-    write_outputs<MATH>(a, i, e, o);
+    write_outputs<MATH>(a, i, e, o, rp);
     store_env(a, i, pid, e);
 }
 
@@ -494,6 +504,7 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_pipe_kernel(const KArg
             if (more) stage_tile(a, next_elem0, st);      // in flight while this tile integrates
         };
         const uint32_t pid = T1D_META_PID(meta);
+        const T rp = prev_risk<MATH>(a, e.prev_cgm);
         StepOut<T> o;
         if (VARIANT == 2) {
             const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
@@ -505,23 +516,44 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_pipe_kernel(const KArg
             ParsScalar<T> p;
             p.load(a.dpar, kMaxPatients, pid0);
             o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
-            write_outputs<MATH>(a, i, e, o);
+            write_outputs<MATH>(a, i, e, o, rp);
             store_env(a, i, pid, e);
         } else if (VARIANT == 3) {
             ParsReg<T> p;
             p.load(lds, (int)pid);                       // 38 ds_reads per tile, then no LDS traffic in the RK4 loop
             o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
-            write_outputs<MATH>(a, i, e, o);
+            write_outputs<MATH>(a, i, e, o, rp);
             store_env(a, i, pid, e);
         } else {
             ParsLds<T> p{lds, (int)pid};
             o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
-            write_outputs<MATH>(a, i, e, o);
+            write_outputs<MATH>(a, i, e, o, rp);
             store_env(a, i, pid, e);
         }
         if (!more) break;
         tile = ntile;
         first = false;
+    }
+}
+
+// Rebuilds the CGM noise block of every env whose next sample(s) -- in minutes (t, t + minutes] -- start a
+// new 150-minute block.  Launched by t1d_step ahead of step_kernel<.., REFILL = false>; touches 4 B per env
+// (the clock) unless a refill is due, which happens once per 150 simulated minutes per env.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void refill_kernel(const KArgs<T> a)
+{
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));
+    if ((int64_t)i >= a.n) return;
+    const int t = at(a.t, i);
+    for (int m = 1; m <= a.minutes; ++m) {
+        const int t1 = t + m;
+        if (t1 % a.sen.st != 0) continue;
+        const int s = 1 + t1 / a.sen.st;
+        if (s % a.S != 0) continue;
+        T e = at(a.ar_e, i);
+        noise_refill<T>(a.pts, a.normals, a.minv, a.episode, a.status, a.n, i, a.env_offset, a.seed, a.n_normals, s / a.S, a.sen, &e);
+        at(a.ar_e, i) = e;
     }
 }
 
@@ -551,8 +583,8 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
         max_bg = o.bg > max_bg ? o.bg : max_bg;
         n_low += o.bg < T(70); n_high += o.bg > T(180);
     }
-    e.prev_cgm = pre_prev_cgm;                   // write_outputs forms the last step's reward from it
-    write_outputs<MATH>(a, i, e, o);
+    e.prev_cgm = pre_prev_cgm;                   // the last step's reward is formed from it
+    write_outputs<MATH>(a, i, e, o, prev_risk<MATH>(a, pre_prev_cgm));
     store_env(a, i, pid, e);
     at(c.integ, i) = integ; at(c.prev, i) = prev;
     if (c.sum_risk) at(c.sum_risk, i) = sum_risk;
@@ -630,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
     const T bg0 = e.x[12] / vg;
     T c[2];
     for (int s = 0; s < 2; ++s) {                    // env.py:126 (history[0]) and env.py:142 (observation)
-        T v = bg0 + noise_sample(a, i, s, e.cur);
+        T v = bg0 + noise_sample<true>(a, i, s, e.cur);
         v = v > a.sen.vmin ? v : a.sen.vmin;
         v = v < a.sen.vmax ? v : a.sen.vmax;
         c[s] = v;
@@ -687,6 +719,7 @@ struct t1d_ctx {
     int pipeline = 0;        // 1 = persistent LDS-DMA pipelined step kernel, 0 = one tile per block
     int n_cu = 256;
     int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
+    int split_refill = 1;    // 1 = noise-block refills run in their own kernel ahead of a refill-free step kernel
     int pipe_stagger = 0;    // s_sleep(127) iterations (~3.4 us each) by which the second half of the persistent grid starts late
 };
 
@@ -826,8 +859,13 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         return T1D_OK;
     }
     if (std::strcmp(name, "params_mode") == 0) {
-        if (value < -1 || value > 2) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be -1, 0, 1 or 2");
+        if (value < -1 || value > 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be -1, 0 or 1");
         c->params_mode = (int)value;
+        return T1D_OK;
+    }
+    if (std::strcmp(name, "split_refill") == 0) {
+        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: split_refill must be 0 or 1");
+        c->split_refill = (int)value;
         return T1D_OK;
     }
     if (std::strcmp(name, "pipe_stagger") == 0) {
@@ -937,7 +975,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     // measured at 1 Mi envs, fp64: VGPR parameters + sub-system-wise RK4 cost ~75 us + 78 us/minute, the LDS-
     // parameter kernel ~55 us + 93 us/minute: equal at one minute per launch, VGPR form ahead beyond
     const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
-    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode == 2 ? 4 : (pmode ? 3 : 1)));
+    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1));
 #define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
 #define T1D_LAUNCH_PIPE(V, TT) hipLaunchKernelGGL((step_pipe_kernel<V, TT>), pgrid, dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
     const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
@@ -959,11 +997,23 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         T1D_HIP(hipGetLastError());
         return T1D_OK;
     }
-    if (b->dtype == T1D_F64) {
-        if (variant == 0) T1D_LAUNCH_STEP(0, double); else if (variant == 1) T1D_LAUNCH_STEP(1, double); else if (variant == 2) T1D_LAUNCH_STEP(2, double); else if (variant == 3) T1D_LAUNCH_STEP(3, double); else T1D_LAUNCH_STEP(4, double);
-    } else {
-        if (variant == 0) T1D_LAUNCH_STEP(0, float); else if (variant == 1) T1D_LAUNCH_STEP(1, float); else if (variant == 2) T1D_LAUNCH_STEP(2, float); else if (variant == 3) T1D_LAUNCH_STEP(3, float); else T1D_LAUNCH_STEP(4, float);
+    // At most one CGM sample per launch (minutes <= sample_time): the noise-block refill runs as its own
+    // kernel ahead of a step kernel compiled without it, unless the caller vouches that none is due.
+    const bool split_refill = variant != 0 && c->split_refill && minutes <= (int)c->sensor[5];
+    if (split_refill && !(b->flags & T1D_BATCH_NO_REFILL_DUE)) {
+        if (b->dtype == T1D_F64) hipLaunchKernelGGL(refill_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s, make_args<double>(c, b, minutes, n_sub));
+        else hipLaunchKernelGGL(refill_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
     }
+#define T1D_LAUNCH_FAST(V, TT) hipLaunchKernelGGL((step_kernel<V, TT, false>), grid_for(b->n), dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
+    if (split_refill) {
+        if (b->dtype == T1D_F64) { if (variant == 1) T1D_LAUNCH_FAST(1, double); else if (variant == 2) T1D_LAUNCH_FAST(2, double); else T1D_LAUNCH_FAST(3, double); }
+        else { if (variant == 1) T1D_LAUNCH_FAST(1, float); else if (variant == 2) T1D_LAUNCH_FAST(2, float); else T1D_LAUNCH_FAST(3, float); }
+    } else if (b->dtype == T1D_F64) {
+        if (variant == 0) T1D_LAUNCH_STEP(0, double); else if (variant == 1) T1D_LAUNCH_STEP(1, double); else if (variant == 2) T1D_LAUNCH_STEP(2, double); else T1D_LAUNCH_STEP(3, double);
+    } else {
+        if (variant == 0) T1D_LAUNCH_STEP(0, float); else if (variant == 1) T1D_LAUNCH_STEP(1, float); else if (variant == 2) T1D_LAUNCH_STEP(2, float); else T1D_LAUNCH_STEP(3, float);
+    }
+#undef T1D_LAUNCH_FAST
 #undef T1D_LAUNCH_STEP
 #undef T1D_LAUNCH_PIPE
     T1D_HIP(hipGetLastError());

@@ -441,21 +441,23 @@ __device__ __forceinline__ void risk_index1(T bg, T& lbgi, T& hbgi, T& ri)
     if (MATH == 0) {
         f = T(1.509) * (t_pow(t_log(bg), T(1.084)) - T(5.381));
     } else {
+        // straight-line on purpose (selects, no branches): independent evaluations interleave and hide the
+        // latency of the log -> log -> exp chain
         const T inf = T(__builtin_huge_val());
-        if (bg > T(1) && bg < inf) {           // log(bg) in (0, inf)
-            const T u = log_core(bg);
-            const T pw = exp_core(T(1.084) * log_core(u));
-            f = T(1.509) * (pw - T(5.381));
-        } else {
-            // numpy: log(1)**p = 0; log(0) = -inf and (-inf)**p = +inf; log(inf)**p = inf; log of a
-            // negative or of a value in (0,1) raised to a non-integer power, and NaN, give NaN
-            const T nan = T(__builtin_nan(""));
-            f = bg == T(1) ? T(1.509) * (T(0) - T(5.381)) : ((bg == T(0) || bg == inf) ? inf : nan);
-        }
+        const T nan = T(__builtin_nan(""));
+        const bool regular = bg > T(1) && bg < inf;            // log(bg) in (0, inf)
+        const T u = log_core(regular ? bg : T(2));
+        const T pw = exp_core(T(1.084) * log_core(u));
+        const T freg = T(1.509) * (pw - T(5.381));
+        // numpy: log(1)**p = 0; log(0) = -inf and (-inf)**p = +inf; log(inf)**p = inf; log of a
+        // negative or of a value in (0,1) raised to a non-integer power, and NaN, give NaN
+        const T fodd = bg == T(1) ? T(1.509) * (T(0) - T(5.381)) : ((bg == T(0) || bg == inf) ? inf : nan);
+        f = regular ? freg : fodd;
     }
     T l = T(0), h = T(0);
-    if (f < T(0)) l = T(10) * f * f;
-    if (f > T(0)) h = T(10) * f * f;
+    const T ff = T(10) * f * f;
+    l = f < T(0) ? ff : T(0);
+    h = f > T(0) ? ff : T(0);
     const T big = sizeof(T) == 8 ? T(1.7976931348623157e308) : T(3.4028234663852886e38);
     l = l < big ? l : big;
     h = h < big ? h : big;

@@ -15,7 +15,7 @@ TOL_ORACLE = 1e-8
 TOL_SCIPY = 1e-3
 
 
-VARIANTS = ("ref", "lds", "reg", "scalar", "pipe_lds", "pipe_reg", "pipe_scalar")
+VARIANTS = ("ref", "lds", "reg", "reg_inline", "scalar", "pipe_lds", "pipe_reg", "pipe_scalar")
 
 
 def _env(variant="scalar", **kw):
@@ -28,7 +28,8 @@ def _env(variant="scalar", **kw):
     env.set_option("math", 0 if variant == "ref" else 1)
     env.set_option("scalar_params", 1 if variant in ("scalar", "pipe_scalar") else 0)
     env.set_option("pipeline", 1 if variant.startswith("pipe") else 0)
-    env.set_option("params_mode", 1 if variant in ("reg", "pipe_reg") else 0)   # default -1 = chosen by minutes
+    env.set_option("params_mode", 1 if variant in ("reg", "reg_inline", "pipe_reg") else 0)
+    env.set_option("split_refill", 0 if variant == "reg_inline" else 1)       # 0: noise-block refill inlined in the step kernel
     return env
 
 
@@ -136,7 +137,7 @@ def test_config2_1024_replicas_vs_scipy(golden, variant):
     assert worst < TOL_SCIPY, worst
 
 
-@pytest.mark.parametrize("variant", ("ref", "lds", "reg", "pipe_lds", "pipe_reg"))
+@pytest.mark.parametrize("variant", ("ref", "lds", "reg", "reg_inline", "pipe_lds", "pipe_reg"))
 def test_all_30_patients_24h_vs_scipy_and_oracle(golden, variant):
     """G2 for every virtual patient in one batch (heterogeneous patient ids in one wave)."""
     import torch
