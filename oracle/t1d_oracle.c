@@ -159,6 +159,109 @@ void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Split fixed-step scheme over one minute (integrator 3) -- the HIP kernel's default integrator.
+ * Same model (t1dpatient.py:119-208), partitioned by what each part of it needs:
+ *   insulin  s = (x5, x9, x10, x11, x6, x7, x8): linear with the minute's constant infusion (:176-198), so it
+ *            is advanced with its exact propagator s(tau) = Phi(tau) [s; u; 1] (Phi from the host, one 7x9
+ *            block per tau = k/ng); the (x >= 0) factors of :179,191,195,198 never switch on this
+ *            non-negative linear flow and are dropped;
+ *   gut      x0, x1 (:133-145): classical RK4, ng steps; F = kgut*x1 is also integrated (Q, RK4 quadrature);
+ *            x2 (:148) is linear in itself with rate kabs (up to 1.23/min): exponential form
+ *            x2' = E x2 + wa F1 + wm (F2+F3)/2 + wb F4 (ETD-RK4 weights for h = 1/ng from the host);
+ *            absorbed mass R = x2(0) - x2 + Q (what has left x2 through kabs since the minute began);
+ *   glucose  x3, x4, x12 (:151-173,201-202): classical RK4, ns = ng/2 steps, on (z3 = x3 - c R, x4, x12),
+ *            c = f/BW: the fast rate-of-appearance forcing then enters only through the argument
+ *            x3 = z3 + c R(tau), with R, X = x6 and XL = x8 taken at the stage times from the parts above.
+ *            The (x >= 0) factors of :167,173,202 are kept.
+ * tab: [ng][7][9] Phi(k/ng), k = 1..ng, then E, wa, wm, wb.   Error vs a tight solve is the same as
+ * RK4(n_sub = ng) on the whole state (tests/test_oracle_golden.py), at ~60 % of its arithmetic.
+ * ---------------------------------------------------------------------------------------- */
+static double o_kgut(const double* p, double qsto, double Dbar)
+{
+    if (Dbar > 0.0) {
+        const double aa = 5.0 / 2.0 / (1.0 - p[T1D_O_B]) / Dbar;
+        const double cc = 5.0 / 2.0 / p[T1D_O_D] / Dbar;
+        return p[T1D_O_KMIN] + (p[T1D_O_KMAX] - p[T1D_O_KMIN]) / 2.0 *
+               (tanh(aa * (qsto - p[T1D_O_B] * Dbar)) - tanh(cc * (qsto - p[T1D_O_D] * Dbar)) + 2.0);
+    }
+    return p[T1D_O_KMAX];
+}
+
+static void o_glucose_rhs(const double* p, const double* y, double cR, double cRdot, double X, double XL,
+                          double* dy)
+{
+    const double x3 = y[0] + cR, x4 = y[1], x12 = y[2];
+    const double EGPt = p[T1D_O_KP1] - p[T1D_O_KP2] * x3 - p[T1D_O_KP3] * XL;
+    const double Et = (x3 > p[T1D_O_KE2]) ? p[T1D_O_KE1] * (x3 - p[T1D_O_KE2]) : 0.0;
+    double d3 = (EGPt > 0.0 ? EGPt : 0.0) - p[T1D_O_FSNC] - Et - p[T1D_O_K1] * x3 + p[T1D_O_K2] * x4;
+    d3 = (x3 >= 0.0) ? d3 : -cRdot;                      /* :167: dx3 = 0  <=>  dz3 = -c R'            */
+    const double Vmt = p[T1D_O_VM0] + p[T1D_O_VMX] * X;
+    double d4 = -Vmt * x4 / (p[T1D_O_KM0] + x4) + p[T1D_O_K1] * x3 - p[T1D_O_K2] * x4;
+    d4 = (x4 >= 0.0) ? d4 : 0.0;                         /* :173 */
+    double d12 = -p[T1D_O_KSC] * x12 + p[T1D_O_KSC] * x3;
+    d12 = (x12 >= 0.0) ? d12 : 0.0;                      /* :202 */
+    dy[0] = d3; dy[1] = d4; dy[2] = d12;
+}
+
+int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
+                       double lf, int ng)
+{
+    if (ng < 2 || ng > 16 || (ng & 1) || !tab) return -1;
+    const int ns = ng / 2;
+    const double d = cho * 1000.0, u = ins * 6000.0 / p[T1D_O_BW], Dbar = lq + lf * 1000.0;
+    const double kmax = p[T1D_O_KMAX], kabs = p[T1D_O_KABS], c = p[T1D_O_F] / p[T1D_O_BW];
+    static const int SI[7] = {5, 9, 10, 11, 6, 7, 8};
+    /* insulin: exact propagation to every tau = k/ng */
+    double aug[9], S[17][7];
+    for (int j = 0; j < 7; ++j) { aug[j] = x[SI[j]]; S[0][j] = aug[j]; }
+    aug[7] = u; aug[8] = 1.0;
+    for (int k = 1; k <= ng; ++k)
+        for (int i = 0; i < 7; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < 9; ++j) a += tab[((k - 1) * 7 + i) * 9 + j] * aug[j];
+            S[k][i] = a;
+        }
+    const double E = tab[ng * 63], wa = tab[ng * 63 + 1], wm = tab[ng * 63 + 2], wb = tab[ng * 63 + 3];
+    /* gut */
+    const double h = 1.0 / (double)ng;
+    double g0 = x[0], g1 = x[1], x2 = x[2], Q = 0.0, R[17], X2[17];
+    R[0] = 0.0; X2[0] = x2;
+    for (int s = 0; s < ng; ++s) {
+        double a0, a1, F1, F2, F3, F4, b0, b1, c0, c1, e0, e1, y0, y1;
+        F1 = o_kgut(p, g0 + g1, Dbar) * g1; a0 = -kmax * g0 + d; a1 = kmax * g0 - F1;
+        y0 = g0 + 0.5 * h * a0; y1 = g1 + 0.5 * h * a1;
+        F2 = o_kgut(p, y0 + y1, Dbar) * y1; b0 = -kmax * y0 + d; b1 = kmax * y0 - F2;
+        y0 = g0 + 0.5 * h * b0; y1 = g1 + 0.5 * h * b1;
+        F3 = o_kgut(p, y0 + y1, Dbar) * y1; c0 = -kmax * y0 + d; c1 = kmax * y0 - F3;
+        y0 = g0 + h * c0; y1 = g1 + h * c1;
+        F4 = o_kgut(p, y0 + y1, Dbar) * y1; e0 = -kmax * y0 + d; e1 = kmax * y0 - F4;
+        g0 += h / 6.0 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
+        g1 += h / 6.0 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
+        Q += h / 6.0 * (F1 + 2.0 * F2 + 2.0 * F3 + F4);
+        x2 = E * x2 + wa * F1 + wm * (0.5 * (F2 + F3)) + wb * F4;
+        X2[s + 1] = x2; R[s + 1] = x[2] - x2 + Q;
+    }
+    /* glucose */
+    const double H = 1.0 / (double)ns;
+    double y[3] = {x[3], x[4], x[12]}, k1[3], k2[3], k3[3], k4[3], w[3];
+    for (int s = 0; s < ns; ++s) {
+        const int ia = 2 * s, im = 2 * s + 1, ib = 2 * s + 2;
+        o_glucose_rhs(p, y, c * R[ia], c * kabs * X2[ia], S[ia][4], S[ia][6], k1);
+        for (int i = 0; i < 3; ++i) w[i] = y[i] + 0.5 * H * k1[i];
+        o_glucose_rhs(p, w, c * R[im], c * kabs * X2[im], S[im][4], S[im][6], k2);
+        for (int i = 0; i < 3; ++i) w[i] = y[i] + 0.5 * H * k2[i];
+        o_glucose_rhs(p, w, c * R[im], c * kabs * X2[im], S[im][4], S[im][6], k3);
+        for (int i = 0; i < 3; ++i) w[i] = y[i] + H * k3[i];
+        o_glucose_rhs(p, w, c * R[ib], c * kabs * X2[ib], S[ib][4], S[ib][6], k4);
+        for (int i = 0; i < 3; ++i) y[i] += H / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    x[0] = g0; x[1] = g1; x[2] = x2;
+    x[3] = y[0] + c * R[ng]; x[4] = y[1]; x[12] = y[2];
+    for (int j = 0; j < 7; ++j) x[SI[j]] = S[ng][j];
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * P2: scipy.integrate.ode(...).set_integrator('dopri5').integrate(t+1)
  *     (patient/t1dpatient.py:276-277 construction, :110-113 one call per minute).
  * Hairer's DOPRI5 driver is re-entered for every minute on [t, t+1]; scipy passes the same
@@ -415,6 +518,9 @@ int t1d_o_step(t1d_o_batch* b, const double* basal, const double* bolus, const d
                 t1d_o_rk4_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub);
             } else if (integrator == 2) {
                 t1d_o_mr_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub / 1000, n_sub % 1000);
+            } else if (integrator == 3) {
+                if (t1d_o_split_minute(p, b->split_tab ? b->split_tab + (size_t)b->pid[i] * b->split_stride : NULL, x,
+                                       to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub) < 0) rc = -1;
             } else {
                 if (t1d_o_dopri5_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i],
                                         &b->h_carry[i], dopri_beta, (double)b->t[i]) < 0) rc = -1;
@@ -453,7 +559,7 @@ double t1d_o_pid(double* integ, double* prev, double cgm, double P, double I, do
  * the G2 open-loop pins (patient/t1dpatient.py:82-116). */
 int t1d_o_patient_minute(const double* p, double* x, double* planned, double* last_qsto, double* last_food,
                          uint8_t* was_eating, double* h_carry, int t, double meal, double insulin,
-                         int integrator, int n_sub, double dopri_beta)
+                         int integrator, int n_sub, double dopri_beta, const double* split_tab)
 {
     double to_eat = 0.0;
     *planned += meal;
@@ -463,5 +569,6 @@ int t1d_o_patient_minute(const double* p, double* x, double* planned, double* la
     *was_eating = (to_eat > 0.0);
     if (integrator == 0) { t1d_o_rk4_minute(p, x, to_eat, insulin, *last_qsto, *last_food, n_sub); return 4 * n_sub; }
     if (integrator == 2) { t1d_o_mr_minute(p, x, to_eat, insulin, *last_qsto, *last_food, n_sub / 1000, n_sub % 1000); return 4 * (n_sub / 1000); }
+    if (integrator == 3) return t1d_o_split_minute(p, split_tab, x, to_eat, insulin, *last_qsto, *last_food, n_sub) < 0 ? -1 : 4 * n_sub;
     return t1d_o_dopri5_minute(p, x, to_eat, insulin, *last_qsto, *last_food, h_carry, dopri_beta, (double)t);
 }

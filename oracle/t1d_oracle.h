@@ -47,6 +47,8 @@ typedef struct {
     int32_t* n_samples;        /* [n] noise samples handed out */
     int32_t* n_draws;          /* [n] normals consumed */
     double* prev_cgm;          /* [n] CGM_hist[-1] before this step (default reward) */
+    const double* split_tab;   /* [n_patients][split_stride] tables of the split scheme (integrator 3) or NULL */
+    int32_t split_stride;      /* = n_sub * 63 + 4 */
 } t1d_o_batch;
 
 typedef struct {
@@ -57,6 +59,8 @@ typedef struct {
 void t1d_o_rhs(const double* p, const double* x, double cho, double ins, double lq, double lf, double* dx);
 void t1d_o_rk4_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int n_sub);
 void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int ng, int ns);
+int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
+                       double lf, int ng);
 int t1d_o_dopri5_minute(const double* p, double* y, double cho, double ins, double lq, double lf,
                         double* h_carry, double beta, double t_start);
 double t1d_o_pump(double amount, double inc, double lo, double hi);
@@ -68,7 +72,7 @@ double t1d_o_pid(double* integ, double* prev, double cgm, double P, double I, do
                  double sample_time);
 int t1d_o_patient_minute(const double* p, double* x, double* planned, double* last_qsto, double* last_food,
                          uint8_t* was_eating, double* h_carry, int t, double meal, double insulin,
-                         int integrator, int n_sub, double dopri_beta);
+                         int integrator, int n_sub, double dopri_beta, const double* split_tab);
 
 #ifdef __cplusplus
 }

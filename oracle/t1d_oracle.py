@@ -104,7 +104,7 @@ class _Batch(C.Structure):
                 ("normals", _d), ("sensor", C.c_double * 8), ("pump", C.c_double * 6),
                 ("x", _d), ("planned", _d), ("last_qsto", _d), ("last_food", _d), ("was_eating", _u),
                 ("t", _i), ("h_carry", _d), ("last_cgm", _d), ("ar_e", _d), ("pts", _d),
-                ("n_samples", _i), ("n_draws", _i), ("prev_cgm", _d)]
+                ("n_samples", _i), ("n_draws", _i), ("prev_cgm", _d), ("split_tab", _d), ("split_stride", C.c_int32)]
 
 
 class _Out(C.Structure):
@@ -131,7 +131,9 @@ def lib():
         L.t1d_o_step.restype = C.c_int
         L.t1d_o_pid.argtypes = [_d, _d] + [C.c_double] * 6; L.t1d_o_pid.restype = C.c_double
         L.t1d_o_patient_minute.argtypes = [_d, _d, _d, _d, _d, _u, _d, C.c_int, C.c_double, C.c_double,
-                                           C.c_int, C.c_int, C.c_double]
+                                           C.c_int, C.c_int, C.c_double, _d]
+        L.t1d_o_split_minute.argtypes = [_d, _d, _d, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.t1d_o_split_minute.restype = C.c_int
         L.t1d_o_patient_minute.restype = C.c_int
         _lib = L
     return _lib
@@ -160,13 +162,46 @@ def risk(bg):
 
 DOPRI_BETA = 0.04     # what the Fortran driver uses when scipy hands it beta = 0.0
 # integrator codes of t1d_oracle.c; "mr" = multirate RK4 with n_sub = ng * 1000 + ns
-_INTEG = {"rk4": 0, "dopri": 1, "mr": 2}
+_INTEG = {"rk4": 0, "dopri": 1, "mr": 2, "split": 3}
+
+
+def split_tables(ptab, n_sub):
+    """Host tables of the split scheme (t1d_oracle.c, integrator 3) for every row of `ptab`:
+    [n_sub][7][9] exact propagators Phi(k/n_sub) of the linear insulin sub-system
+    s = (x5, x9, x10, x11, x6, x7, x8) augmented with (u, 1)  (t1dpatient.py:176-198), from
+    scipy.linalg.expm, then the ETD-RK4 weights (E, wa, wm, wb) of x2' = -kabs x2 + F for
+    h = 1/n_sub by Gauss-Legendre quadrature of the quadratic interpolant against exp(-kabs (h-s))."""
+    from scipy.linalg import expm
+    ptab = np.atleast_2d(ptab)
+    out = np.zeros((ptab.shape[0], n_sub * 63 + 4))
+    gx, gw = np.polynomial.legendre.leggauss(32)
+    h = 1.0 / n_sub
+    s = (gx + 1.0) * h / 2.0; w = gw * h / 2.0
+    La = (s - h / 2) * (s - h) / ((0 - h / 2) * (0 - h))
+    Lm = (s - 0) * (s - h) / ((h / 2) * (h / 2 - h))
+    Lb = (s - 0) * (s - h / 2) / (h * (h / 2))
+    for r, p in enumerate(ptab):
+        g = lambda k: p[IDX[k]]
+        A = np.zeros((9, 9))
+        A[0, 0] = -(g("m2") + g("m4")); A[0, 1] = g("m1"); A[0, 2] = g("ka1"); A[0, 3] = g("ka2")     # x5  :176
+        A[1, 1] = -(g("m1") + g("m30")); A[1, 0] = g("m2")                                            # x9  :190
+        A[2, 2] = -(g("ka1") + g("kd")); A[2, 7] = 1.0                                                # x10 :194
+        A[3, 2] = g("kd"); A[3, 3] = -g("ka2")                                                        # x11 :197
+        A[4, 4] = -g("p2u"); A[4, 0] = g("p2u") / g("Vi"); A[4, 8] = -g("p2u") * g("Ib")              # x6  :182
+        A[5, 5] = -g("ki"); A[5, 0] = g("ki") / g("Vi")                                               # x7  :185
+        A[6, 6] = -g("ki"); A[6, 5] = g("ki")                                                         # x8  :187
+        for k in range(1, n_sub + 1):
+            out[r, (k - 1) * 63:k * 63] = expm(A * (k * h))[:7].ravel()
+        ker = np.exp(-g("kabs") * (h - s))
+        out[r, n_sub * 63:] = (np.exp(-g("kabs") * h), (ker * La * w).sum(), (ker * Lm * w).sum(), (ker * Lb * w).sum())
+    return np.ascontiguousarray(out)
 
 
 class PatientOracle:
     """T1DPatient.step restated (patient only; no pump/sensor) -- pins G2."""
 
     def __init__(self, prow, x0=None):
+        self._split = {}
         self.p = np.ascontiguousarray(prow, dtype=np.float64)
         self.x = np.array(self.p[:13] if x0 is None else x0, dtype=np.float64)
         self.planned = C.c_double(0.0); self.lq = C.c_double(self.x[0] + self.x[1]); self.lf = C.c_double(0.0)
@@ -174,12 +209,17 @@ class PatientOracle:
         self.nfcn = 0
 
     def step(self, meal, insulin, integrator="rk4", n_sub=4, beta=DOPRI_BETA):
+        tab = None
+        if integrator == "split":
+            if n_sub not in self._split:
+                self._split[n_sub] = split_tables(self.p, n_sub)[0]
+            tab = _p(self._split[n_sub])
         r = lib().t1d_o_patient_minute(_p(self.p), _p(self.x), C.byref(self.planned), C.byref(self.lq),
                                        C.byref(self.lf), C.byref(self.eat), C.byref(self.h), self.t,
                                        float(meal), float(insulin), _INTEG[integrator],
-                                       int(n_sub), float(beta))
+                                       int(n_sub), float(beta), tab)
         if r < 0:
-            raise RuntimeError("oracle DOPRI5 failed")
+            raise RuntimeError("oracle integrator failed")
         self.nfcn = r
         self.t += 1
         return self.x
@@ -215,6 +255,9 @@ class OracleEnv:
         for k in range(6): b.pump[k] = self.pump[k]
         for k in ("x", "planned", "last_qsto", "last_food", "h_carry", "last_cgm", "ar_e", "pts", "prev_cgm"):
             setattr(b, k, _p(getattr(self, k)))
+        if integrator == "split":
+            self.split_tab = split_tables(self.ptab, n_sub)
+            b.split_tab = _p(self.split_tab); b.split_stride = self.split_tab.shape[1]
         b.was_eating = _p(self.was_eating, _u); b.t = _p(self.t, _i)
         b.n_samples = _p(self.n_samples, _i); b.n_draws = _p(self.n_draws, _i)
         o = self._o = _Out()

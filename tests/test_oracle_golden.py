@@ -92,7 +92,7 @@ def test_env_step_dopri_matches_reference(golden, sensor, seed, pname):
     nstep = len(g["basal_" + tag])
     cho = O.custom_scenario_cho(g["scen_hours"], g["scen_grams"], nstep * st)
     worst = {}
-    for integ, tol in (("dopri", 1e-8), ("rk4", 1e-3)):
+    for integ, tol in (("dopri", 1e-8), ("rk4", 1e-3), ("split", 1e-3)):
         env = O.OracleEnv([names.index(pname)], sensor=sensor, normals=g["randn_" + tag][:, None], integrator=integ, n_sub=4)
         r0 = env.reset()
         assert abs(r0["cgm"][0] - float(g["reset_cgm_" + tag])) < 1e-12
@@ -101,7 +101,7 @@ def test_env_step_dopri_matches_reference(golden, sensor, seed, pname):
         w = 0.0
         for k in range(nstep):
             o = env.step(g["basal_" + tag][k], g["bolus_" + tag][k], cho[k * st:(k + 1) * st, None])
-            if g["bg_" + tag][k] < 20.0 and integ == "rk4":
+            if g["bg_" + tag][k] < 20.0 and integ != "dopri":
                 break            # RHS non-negativity clamp regime: fixed-step RK4 is not held to 1e-3 there
             w = max(w, abs(o["bg"][0] - g["bg_" + tag][k]), abs(o["cgm"][0] - g["cgm_" + tag][k]))
             assert o["meal"][0] == pytest.approx(g["meal_" + tag][k], abs=1e-13)
@@ -124,7 +124,7 @@ def test_open_loop_24h_all_patients(golden):
     names, tab = O.patient_table()
     meal = dict(zip(g["meal_minute"].tolist(), g["meal_grams"].tolist()))
     mult = g["action_mult"]
-    for integ, tol in (("dopri", 2e-5), ("rk4", 1e-3)):
+    for integ, tol in (("dopri", 2e-5), ("rk4", 1e-3), ("split", 1e-3)):
         worst = 0.0
         for ip in range(30):
             p = O.PatientOracle(tab[ip])
@@ -160,9 +160,10 @@ def test_upstream_golden_file_closed_loop():
     assert np.abs(hist["CHO"] - ref["CHO"][:-1]).max() < 1e-12
     assert np.abs(hist["insulin"] - ref["insulin"][:-1]).max() < 1e-9
     # and through RK4(4): BASELINE's bar on the glucose columns
-    hist4, _ = O.closed_loop("adolescent#001", "Dexcom", 1, 1, 960, _bb("adolescent#001"), integrator="rk4", n_sub=4)
-    assert np.abs(hist4["BG"] - ref["BG"]).max() < 1e-3
-    assert np.abs(hist4["CGM"] - ref["CGM"]).max() < 1e-3
+    for integ in ("rk4", "split"):
+        hist4, _ = O.closed_loop("adolescent#001", "Dexcom", 1, 1, 960, _bb("adolescent#001"), integrator=integ, n_sub=4)
+        assert np.abs(hist4["BG"] - ref["BG"]).max() < 1e-3, integ
+        assert np.abs(hist4["CGM"] - ref["CGM"]).max() < 1e-3, integ
 
 
 def test_config1_adult001_bb_24h(golden):
