@@ -176,8 +176,23 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * "pipeline": 1 = t1d_step runs the persistent kernel that streams the next tile of envs into LDS with
  * LDS-DMA while it integrates the current one (needs the packed state layout and n % 256 == 0);
  * default 0 (one 256-env tile per workgroup): measured equal within noise in round 1.
- * "pipe_blocks": grid of the persistent kernel (0 = 2 x compute units). */
+ * "pipe_blocks": grid of the persistent kernel (0 = 2 x compute units).
+ * "integrator": how `n_sub` sub-steps per minute replace scipy's dopri5 (t1dpatient.py:110-113,276):
+ * 0 = classical RK4 on all 13 states; 1 = the split scheme -- exact propagator for the linear insulin
+ * sub-system (:176-198), RK4 at n_sub steps for the stomach with the gut compartment in exponential form
+ * (:133-148), RK4 at n_sub/2 steps for the glucose states with the absorbed mass shifted into the state
+ * (:151-173,201-202) -- which needs math = 1 and n_sub in {2, 4, 6, 8}; -1 (default) = split whenever
+ * those hold, classical RK4 otherwise.  Both meet 1e-3 mg/dL against scipy at n_sub = 4 (same error:
+ * it is set by the gastric-emptying term, which both integrate alike); the persistent kernel
+ * ("pipeline") integrates with classical RK4 only. */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
+
+/* Host-only helper (no device needed): the tables of the split integrator for one patient row
+ * (T1D_P_* order, n_cols == T1D_P_NCOLS) and n_sub in {2, 4, 6, 8}: 14 n_sub + 21 entries of the
+ * insulin propagator Phi(k/n_sub) (layout in simglucose_amd/csrc/t1d_device.hpp) followed by the four
+ * weights E, wa, wm, wb of the exponential gut update; out_len >= 14 n_sub + 25.  What t1d_step
+ * uploads; exposed so that the tables can be checked against an independent matrix exponential. */
+int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
 
 /* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after
  * T1DSimEnv.reset(): cgm = CGM sample #1, prev_cgm = CGM sample #0, bg/lbgi/hbgi/risk of the

@@ -32,11 +32,12 @@ template <typename T> struct KArgs {
     const T* normals; const T* x0_override;
     T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin;
     const T* dpar;          // [DP_COUNT][kMaxPatients] derived patient constants
+    const T* prop;          // [prop_rows][np_pad] insulin propagator of the split integrator (kPropRows(n_sub) rows)
     const double* x0tab;    // [13][np]
     const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
     int* status;
     SensorC<T> sen; PumpC<T> pump;
-    int np, S, n_meals, n_normals, minutes, n_sub, flags, stagger;
+    int np, S, n_meals, n_normals, minutes, n_sub, flags, stagger, prop_rows, np_pad;
 };
 
 template <typename T> struct PidArgs {
@@ -75,10 +76,19 @@ template <typename T> struct Env {
 template <typename T> struct StepOut { T cgm, bg, meal, ins; };
 
 template <typename T>
-__device__ __forceinline__ void stage_pars(const KArgs<T>& a, T* lds)
+__device__ __forceinline__ void stage_pars(const KArgs<T>& a, T* lds, int rows = DP_COUNT)
 {
-    const int tot = DP_COUNT * kMaxPatients;
+    const int tot = rows * kMaxPatients;
     for (int j = threadIdx.x; j < tot; j += blockDim.x) lds[j] = a.dpar[j];
+    __syncthreads();
+}
+
+// the split integrator's propagator table into (dynamic) LDS; same [rows][np_pad] layout as in memory
+template <typename T>
+__device__ __forceinline__ void stage_prop(const KArgs<T>& a, T* lds)
+{
+    const int tot = a.prop_rows * a.np_pad;
+    for (int j = threadIdx.x; j < tot; j += blockDim.x) lds[j] = a.prop[j];
     __syncthreads();
 }
 
@@ -261,9 +271,9 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `pre_rk4` runs once, immediately before the first minute's RK4 sub-steps: from there to the end of
 // the integration the wave issues no vector-memory instruction, which is where the persistent kernel
 // starts the LDS-DMA of its next tile.
-template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false, bool REFILL = true>
+template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false, bool REFILL = true, typename PR = NoProp>
 __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
-                                                T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook())
+                                                T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook(), PR pr = PR())
 {
     T q_basal, q_bolus;
     if (a.flags & (T1D_BATCH_NO_PUMP | 0x200)) { // T1DPatient.step driven directly: insulin = basal + bolus as given
@@ -283,7 +293,7 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
         MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
         // every load this minute issued is needed by the integration anyway: drain them HERE, on every
         // path, so that the compiler's own wait cannot land behind the hook's (invisible) DMA instructions
-        p.pin();
+        if constexpr (PR::kSplit) p.pin_split(); else p.pin();
         {   // volatile asms keep their order: everything the RK4 loop consumes is computed (and any spilled
             // operand reloaded) BEFORE the hook below issues its DMA
             T aa = u.aa, cc = u.cc, bD = u.bD, dD = u.dD, dmg = u.d_mg, ins = u.ins;
@@ -292,7 +302,8 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
         }
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
         if (m == 0) pre_rk4();
-        if (!(a.flags & 0x800)) rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP);
+        if constexpr (PR::kSplit) { if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub); }
+        else { if (!(a.flags & 0x800)) rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP); }
         e.t += 1;
         const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
         const T cgm = measure_apply(a, e, gsub, noise, due);                      // env.py:62
@@ -337,14 +348,25 @@ __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env
 //         1: fast arithmetic, parameters re-read from LDS per RHS evaluation (any patient layout)
 //         2: fast arithmetic, wave-uniform patient, parameters in SGPRs (T1D_BATCH_WAVE_UNIFORM)
 //         3: fast arithmetic, parameters gathered once per lane into VGPRs (any patient layout)
+//         4: as 3, split integrator (t1d_device.hpp) with the insulin propagator staged in LDS
+//         5: as 1, split integrator
 template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
+template <int VARIANT> struct VariantInfo {
+    static constexpr bool split = VARIANT == 4 || VARIANT == 5;
+    static constexpr bool lds_pars = VARIANT == 0 || VARIANT == 1 || VARIANT == 5;
+    static constexpr bool reg_pars = VARIANT == 3 || VARIANT == 4;
+};
+extern __shared__ __align__(16) unsigned char t1d_dyn_lds[];
 
 template <int VARIANT, typename T, bool REFILL = true>
 __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> a)
 {
     constexpr int MATH = VariantMath<VARIANT>::value;
-    __shared__ T lds[(VARIANT == 2 || VARIANT == 3) ? 1 : DP_COUNT * kMaxPatients];
-    if (VARIANT < 2) stage_pars(a, lds);
+    using VI = VariantInfo<VARIANT>;
+    constexpr int kParRows = VI::split ? DP_COUNT : DP_RK4_COUNT;
+    __shared__ T lds[VI::lds_pars ? kParRows * kMaxPatients : 1];
+    if (VI::lds_pars) stage_pars(a, lds, kParRows);
+    if (VI::split) stage_prop(a, (T*)t1d_dyn_lds);
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
     if ((int64_t)i >= a.n) return;
@@ -356,13 +378,22 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
     const T rp = prev_risk<MATH>(a, e.prev_cgm);
     StepOut<T> o;
-    if (VARIANT == 2) {
+    if constexpr (VARIANT == 4) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        PropLds<T> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL, PropLds<T>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
+    } else if constexpr (VARIANT == 5) {
+        ParsLds<T> p{lds, (int)pid};
+        PropLds<T> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL, PropLds<T>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
+    } else if constexpr (VARIANT == 2) {
         const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
         if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
         ParsScalar<T> p;
         p.load(a.dpar, kMaxPatients, pid0);
         o = step_body<MATH, T, ParsScalar<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
-    } else if (VARIANT == 3) {
+    } else if constexpr (VARIANT == 3) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
         o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
@@ -372,6 +403,116 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     }
     write_outputs<MATH>(a, i, e, o, rp);
     store_env(a, i, pid, e);
+}
+
+// ---- single-minute step, split integrator, persistent blocks -----------------------------------------
+// The launch the headline workload makes a million times: one simulated minute per env.step (1-min sensors),
+// no noise-block refill due (refill_kernel ran, or the host vouched).  Differences from step_kernel:
+//   * blocks are persistent (grid = what is resident) and walk tiles of 256 envs, so the parameter and
+//     propagator tables are staged into LDS once per block instead of once per 256 envs, compactly
+//     (row stride 32 or 64 patients, a compile-time constant: every table read is a ds_read with an
+//     immediate offset);
+//   * everything the integration does not need is stored BEFORE it (meal bookkeeping, clock, meal cursor,
+//     insulin/meal outputs), so that only the 13 states, the drawn noise and the previous risk are alive
+//     across the sub-step loops -- which is what lets four waves share a SIMD (<= 128 VGPRs) where
+//     step_kernel needs ~230.
+#ifndef T1D_S1_WAVES
+#define T1D_S1_WAVES 3
+#endif
+template <bool REG, typename T, int STRIDE>
+__global__ __launch_bounds__(kBlock, T1D_S1_WAVES) void step1_kernel(const KArgs<T> a, int ntiles)
+{
+    T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
+    T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
+    for (int j = threadIdx.x; j < DP_COUNT * STRIDE; j += kBlock) {
+        const int r = j / STRIDE, c = j % STRIDE;
+        ldp[j] = c < a.np ? a.dpar[r * kMaxPatients + c] : T(0);
+    }
+    for (int j = threadIdx.x; j < a.prop_rows * STRIDE; j += kBlock) {
+        const int r = j / STRIDE, c = j % STRIDE;
+        lpr[j] = c < a.np ? a.prop[r * a.np_pad + c] : T(0);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const unsigned i = (unsigned)tile * kBlock + threadIdx.x;
+        __builtin_assume(i < (1u << 28));
+        if ((int64_t)i >= a.n) break;
+        const uint32_t meta = at(a.meta, i);
+        const uint32_t pid = T1D_META_PID(meta);
+        Env<T> e;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
+        e.planned = at(a.planned, i); e.lq = at(a.last_qsto, i); e.lf = at(a.last_food, i);
+        e.t = at(a.t, i);
+        e.next_meal = a.next_meal ? at(a.next_meal, i) : 0;
+        e.next_meal_loaded = e.next_meal;
+        e.eating = (meta & T1D_META_EATING) != 0;
+        e.cursor = (int)T1D_META_CURSOR(meta);
+        const T basal = at(a.basal, i);
+        const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+        T q_basal, q_bolus;
+        if (a.flags & T1D_BATCH_NO_PUMP) {
+            q_basal = basal; q_bolus = a.bolus ? bolus : T(0);
+        } else {
+            q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
+            q_bolus = a.pump.min_bolus > T(0) ? a.pump.min_bolus : T(0);
+            if (a.bolus) q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
+        }
+        const T insulin = q_basal + q_bolus;
+        const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
+        ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
+        MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+        // bookkeeping is final for this minute: store it now
+        at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
+        at(a.t, i) = e.t + 1;
+        if (a.next_meal && e.next_meal != e.next_meal_loaded) at(a.next_meal, i) = e.next_meal;
+        at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+        if (a.meal) at(a.meal, i) = meal;
+        if (a.insulin) at(a.insulin, i) = insulin;
+        {
+            PropLdsS<T, STRIDE> pr{lpr, (int)pid};
+            if (REG) {
+                ParsReg<T> p;
+#pragma unroll
+                for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
+                p.pin_split();
+                split_minute(p, pr, u, e.x, a.n_sub);
+            } else {
+                split_minute(pl, pr, u, e.x, a.n_sub);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
+        // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.pts, a.n, 22 + k), i);
+        T last_cgm = at(a.last_cgm, i);
+        const T prev_cgm = at(a.prev_cgm, i);
+        bool due;
+        const T noise = measure_noise<false>(a, i, e, due);       // e.t is still the minute's start: sample for t + 1
+        const T rp = prev_risk<1>(a, prev_cgm);
+        const T gsub = e.x[12] * pl(DP_IVG);                                                       // t1dpatient.py:217-218
+        if (due) {                                                                                 // cgm.py:26-36
+            T c = gsub + noise;
+            c = c > a.sen.vmin ? c : a.sen.vmin;
+            c = c < a.sen.vmax ? c : a.sen.vmax;
+            last_cgm = c;
+            at(a.last_cgm, i) = c;
+        }
+        T l, h, r, rc = T(0);
+        if (!(a.flags & 0x100)) risk_index1<1>(last_cgm, l, h, rc);
+        at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
+        at(a.prev_cgm, i) = last_cgm;
+        at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
+        at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
+        if (a.lbgi || a.hbgi || a.risk) {
+            risk_index1<1>(gsub, l, h, r);                                                         // env.py:85
+            if (a.lbgi) at(a.lbgi, i) = l;
+            if (a.hbgi) at(a.hbgi, i) = h;
+            if (a.risk) at(a.risk, i) = r;
+        }
+        if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+    }
 }
 
 // ---- persistent, software-pipelined step ---------------------------------------------------------
@@ -465,9 +606,9 @@ template <int VARIANT, typename T>
 __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_pipe_kernel(const KArgs<T> a)
 {
     constexpr int MATH = 1;
-    __shared__ T lds[VARIANT == 2 ? 1 : DP_COUNT * kMaxPatients];
+    __shared__ T lds[VARIANT == 2 ? 1 : DP_RK4_COUNT * kMaxPatients];
     __shared__ Stage<T> stage[kBlock / 64];
-    if (VARIANT != 2) stage_pars(a, lds);
+    if (VARIANT != 2) stage_pars(a, lds, DP_RK4_COUNT);
     const unsigned ntiles = (unsigned)(a.n / kBlock);
     unsigned tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -557,8 +698,8 @@ __global__ __launch_bounds__(kBlock) void refill_kernel(const KArgs<T> a)
     }
 }
 
-template <int VARIANT, typename T, typename P>
-__device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>& c, P& p, unsigned i, uint32_t pid, Env<T>& e)
+template <int VARIANT, typename T, typename P, typename PR = NoProp>
+__device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>& c, P& p, unsigned i, uint32_t pid, Env<T>& e, PR pr = PR())
 {
     constexpr int MATH = VariantMath<VARIANT>::value;
     T obs = at(a.cgm, i);
@@ -574,7 +715,7 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
         const T u = c.P * (obs - c.target) + c.I * integ + c.D * (obs - prev) / st;
         prev = obs;
         integ += (obs - c.target) * st;
-        o = step_body<MATH>(a, p, i, e, u, T(0), true);
+        o = step_body<MATH, T, P, NoHook, false, true, PR>(a, p, i, e, u, T(0), true, NoHook(), pr);
         obs = o.cgm;
         pre_prev_cgm = e.prev_cgm;
         e.prev_cgm = o.cgm;                      // CGM history advances every step
@@ -597,8 +738,11 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
 template <int VARIANT, typename T>
 __global__ __launch_bounds__(kBlock, T1D_WAVES) void rollout_pid_kernel(const KArgs<T> a, const PidArgs<T> c)
 {
-    __shared__ T lds[VARIANT >= 2 ? 1 : DP_COUNT * kMaxPatients];
-    if (VARIANT < 2) stage_pars(a, lds);
+    using VI = VariantInfo<VARIANT>;
+    constexpr int kParRows = VI::split ? DP_COUNT : DP_RK4_COUNT;
+    __shared__ T lds[VI::lds_pars ? kParRows * kMaxPatients : 1];
+    if (VI::lds_pars) stage_pars(a, lds, kParRows);
+    if (VI::split) stage_prop(a, (T*)t1d_dyn_lds);
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
     if ((int64_t)i >= a.n) return;
@@ -606,13 +750,20 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void rollout_pid_kernel(const KA
     const uint32_t pid = T1D_META_PID(meta);
     Env<T> e;
     load_env(a, i, meta, e);
-    if (VARIANT == 2) {
+    if constexpr (VARIANT == 4) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+    } else if constexpr (VARIANT == 5) {
+        ParsLds<T> p{lds, (int)pid};
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+    } else if constexpr (VARIANT == 2) {
         const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
         if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
         ParsScalar<T> p;
         p.load(a.dpar, kMaxPatients, pid0);
         rollout_body<VARIANT>(a, c, p, i, pid, e);
-    } else if (VARIANT == 3) {
+    } else if constexpr (VARIANT == 3) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
         rollout_body<VARIANT>(a, c, p, i, pid, e);
@@ -721,6 +872,13 @@ struct t1d_ctx {
     int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
     int split_refill = 1;    // 1 = noise-block refills run in their own kernel ahead of a refill-free step kernel
     int pipe_stagger = 0;    // s_sleep(127) iterations (~3.4 us each) by which the second half of the persistent grid starts late
+    int single_minute_kernel = 1;   // 1 = minutes == 1 launches of the split integrator use the persistent early-store kernel
+    int integrator = -1;     // 0 = classical RK4 on all 13 states, 1 = split scheme, -1 = split whenever n_sub allows it
+    int split_nsub = 0;      // n_sub the split tables on the device were built for (0 = none yet)
+    int np_pad = 0;
+    double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
+    std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
+    std::vector<double> dpar;    // host copy of the derived-parameter table
 };
 
 static thread_local std::string g_err;
@@ -762,6 +920,146 @@ static std::vector<double> spline_second_derivative_operator()
         }
     }
     return B;
+}
+
+
+// ---- host tables of the split integrator ------------------------------------------------------------
+// exp(A) for a small dense matrix: scaling and squaring with a degree-16 Taylor polynomial
+static void mat_expm(int n, const double* A, double* E)
+{
+    double nrm = 0.0;
+    for (int i = 0; i < n; ++i) { double r = 0.0; for (int j = 0; j < n; ++j) r += std::fabs(A[i * n + j]); nrm = std::max(nrm, r); }
+    int sq = 0;
+    while (nrm > 0.03125 && sq < 60) { nrm *= 0.5; ++sq; }
+    const double sc = std::ldexp(1.0, -sq);
+    std::vector<double> B(n * n), term(n * n, 0.0), tmp(n * n);
+    for (int k = 0; k < n * n; ++k) B[k] = A[k] * sc;
+    for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) E[i * n + j] = (i == j); term[i * n + i] = 1.0; }
+    for (int d = 1; d <= 16; ++d) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < n; ++k) v += term[i * n + k] * B[k * n + j];
+                tmp[i * n + j] = v / (double)d;
+            }
+        term = tmp;
+        for (int k = 0; k < n * n; ++k) E[k] += term[k];
+    }
+    for (int q = 0; q < sq; ++q) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < n; ++k) v += E[i * n + k] * E[k * n + j];
+                tmp[i * n + j] = v;
+            }
+        for (int k = 0; k < n * n; ++k) E[k] = tmp[k];
+    }
+}
+
+// One patient row -> kPropRows(ng) propagator entries (layout: t1d_device.hpp) followed by the four x2
+// weights E, wa, wm, wb.  The insulin sub-system in the order s = (x5, x9, x10, x11, x6, x7, x8, u, 1)
+// (t1dpatient.py:176-198); weights of x2' = -kabs x2 + F (:148) for h = 1/ng from the moments
+// I_k = int_0^1 exp(-z (1 - s)) s^k ds = sum_j (-z)^j k! / (k + j + 1)!,  z = kabs h, of the quadratic
+// through F(0), F(h/2), F(h).
+static void split_tables_row(const double* r, int ng, double* out)
+{
+    double A[81] = {0.0};
+    auto at = [&](int i, int j) -> double& { return A[i * 9 + j]; };
+    at(0, 0) = -(r[T1D_P_M2] + r[T1D_P_M4]); at(0, 1) = r[T1D_P_M1]; at(0, 2) = r[T1D_P_KA1]; at(0, 3) = r[T1D_P_KA2];
+    at(1, 1) = -(r[T1D_P_M1] + r[T1D_P_M30]); at(1, 0) = r[T1D_P_M2];
+    at(2, 2) = -(r[T1D_P_KA1] + r[T1D_P_KD]); at(2, 7) = 1.0;
+    at(3, 2) = r[T1D_P_KD]; at(3, 3) = -r[T1D_P_KA2];
+    at(4, 4) = -r[T1D_P_P2U]; at(4, 0) = r[T1D_P_P2U] / r[T1D_P_VI]; at(4, 8) = -r[T1D_P_P2U] * r[T1D_P_IB];
+    at(5, 5) = -r[T1D_P_KI]; at(5, 0) = r[T1D_P_KI] / r[T1D_P_VI];
+    at(6, 6) = -r[T1D_P_KI]; at(6, 5) = r[T1D_P_KI];
+    double Ah[81], Ph[81], Pk[81], tmp[81];
+    const double h = 1.0 / (double)ng;
+    for (int k = 0; k < 81; ++k) Ah[k] = A[k] * h;
+    mat_expm(9, Ah, Ph);
+    std::memcpy(Pk, Ph, sizeof(Pk));
+    static const int c6[7] = {4, 0, 1, 2, 3, 7, 8};      // x6 <- x6, x5, x9, x10, x11, u, 1
+    static const int c8[7] = {6, 5, 0, 1, 2, 3, 7};      // x8 <- x8, x7, x5, x9, x10, x11, u
+    for (int k = 1; k <= ng; ++k) {
+        double* o = out + (k - 1) * 14;
+        for (int j = 0; j < 7; ++j) { o[j] = Pk[4 * 9 + c6[j]]; o[7 + j] = Pk[6 * 9 + c8[j]]; }
+        if (k == ng) break;
+        for (int i = 0; i < 9; ++i)
+            for (int j = 0; j < 9; ++j) {
+                double v = 0.0;
+                for (int q = 0; q < 9; ++q) v += Ph[i * 9 + q] * Pk[q * 9 + j];
+                tmp[i * 9 + j] = v;
+            }
+        std::memcpy(Pk, tmp, sizeof(Pk));
+    }
+    double* t = out + 14 * ng;                           // tail: Phi(1)
+    static const int c5[5] = {0, 1, 2, 3, 7};
+    for (int j = 0; j < 5; ++j) { t[j] = Pk[0 * 9 + c5[j]]; t[5 + j] = Pk[1 * 9 + c5[j]]; }
+    t[10] = Pk[2 * 9 + 2]; t[11] = Pk[2 * 9 + 7];
+    t[12] = Pk[3 * 9 + 2]; t[13] = Pk[3 * 9 + 3]; t[14] = Pk[3 * 9 + 7];
+    static const int c7[6] = {5, 0, 1, 2, 3, 7};
+    for (int j = 0; j < 6; ++j) t[15 + j] = Pk[5 * 9 + c7[j]];
+    const double z = r[T1D_P_KABS] * h;
+    double I[3];
+    for (int k = 0; k < 3; ++k) {
+        double term = 1.0, sum = 0.0;                    // term = (-z)^j k! / (k + j + 1)!
+        for (int q = 1; q <= k + 1; ++q) term /= (double)q;          // j = 0: k!/(k+1)! = 1/(k+1) -> start from 1/(k+1)!, times k!
+        for (int q = 1; q <= k; ++q) term *= (double)q;
+        for (int j = 0; j < 60; ++j) {
+            sum += term;
+            term *= -z / (double)(k + j + 2);
+            if (std::fabs(term) < 1e-30) break;
+        }
+        I[k] = sum;
+    }
+    double* w = out + kPropRows(ng);
+    w[0] = std::exp(-z);
+    w[1] = h * (2.0 * I[2] - 3.0 * I[1] + I[0]);
+    w[2] = h * (-4.0 * I[2] + 4.0 * I[1]);
+    w[3] = h * (2.0 * I[2] - I[1]);
+}
+
+extern "C" int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len)
+{
+    if (!patient_row || !out) return fail(T1D_E_INVALID, "t1d_split_tables: NULL argument");
+    if (n_cols != T1D_P_NCOLS) return fail(T1D_E_INVALID, "t1d_split_tables: n_cols must be T1D_P_NCOLS (45)");
+    if (n_sub < 2 || n_sub > 8 || (n_sub & 1)) return fail(T1D_E_INVALID, "t1d_split_tables: n_sub must be 2, 4, 6 or 8");
+    if (out_len < kPropRows(n_sub) + 4) return fail(T1D_E_INVALID, "t1d_split_tables: out_len < 14 n_sub + 25");
+    split_tables_row(patient_row, n_sub, out);
+    return T1D_OK;
+}
+
+// (re)build the device tables of the split integrator for n_sub sub-steps per minute
+static int ensure_split(t1d_ctx* c, int ng)
+{
+    if (c->split_nsub == ng) return T1D_OK;
+    T1D_HIP(hipDeviceSynchronize());                     // kernels in flight may still be reading the old tables
+    const int rows = kPropRows(ng), npp = c->np_pad;
+    std::vector<double> prop((size_t)rows * npp, 0.0), one((size_t)rows + 4);
+    for (int j = 0; j < c->np; ++j) {
+        split_tables_row(c->ptab.data() + (size_t)j * T1D_P_NCOLS, ng, one.data());
+        for (int k = 0; k < rows; ++k) prop[(size_t)k * npp + j] = one[k];
+        c->dpar[(size_t)DP_X2E * kMaxPatients + j] = one[rows];
+        c->dpar[(size_t)DP_X2WA * kMaxPatients + j] = one[rows + 1];
+        c->dpar[(size_t)DP_X2WM * kMaxPatients + j] = one[rows + 2];
+        c->dpar[(size_t)DP_X2WB * kMaxPatients + j] = one[rows + 3];
+    }
+    std::vector<float> propf(prop.begin(), prop.end()), dpf(c->dpar.begin(), c->dpar.end());
+    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); c->d_prop64 = nullptr; c->d_prop32 = nullptr;
+    T1D_HIP(hipMalloc((void**)&c->d_prop64, prop.size() * 8));
+    T1D_HIP(hipMalloc((void**)&c->d_prop32, propf.size() * 4));
+    T1D_HIP(hipMemcpy(c->d_prop64, prop.data(), prop.size() * 8, hipMemcpyHostToDevice));
+    T1D_HIP(hipMemcpy(c->d_prop32, propf.data(), propf.size() * 4, hipMemcpyHostToDevice));
+    T1D_HIP(hipMemcpy(c->d_par64, c->dpar.data(), c->dpar.size() * 8, hipMemcpyHostToDevice));
+    T1D_HIP(hipMemcpy(c->d_par32, dpf.data(), dpf.size() * 4, hipMemcpyHostToDevice));
+    c->split_nsub = ng;
+    return T1D_OK;
+}
+
+// which integrator a call with n_sub sub-steps uses: the split scheme needs fast math and an even n_sub <= 8
+static bool use_split(const t1d_ctx* c, int n_sub)
+{
+    const bool can = c->math != 0 && n_sub >= 2 && n_sub <= 8 && !(n_sub & 1);
+    return can && c->integrator != 0;
 }
 
 extern "C" int t1d_abi_version(void) { return T1D_ABI_VERSION; }
@@ -818,8 +1116,12 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
             set(DP_KA1KD, r[T1D_P_KA1] + r[T1D_P_KD]); set(DP_KD, r[T1D_P_KD]); set(DP_KSC, r[T1D_P_KSC]);
             set(DP_INSC, 6000.0 / r[T1D_P_BW]); set(DP_VG, r[T1D_P_VG]); set(DP_IVI, 1.0 / r[T1D_P_VI]); set(DP_IVG, 1.0 / r[T1D_P_VG]);
             set(DP_DK, r[T1D_P_KMAX] - r[T1D_P_KMIN]);
+            set(DP_CF, r[T1D_P_F] / r[T1D_P_BW]);
             for (int k = 0; k < 13; ++k) x0[(size_t)k * np + j] = r[T1D_P_X0 + k];
         }
+        c->ptab.assign(ptab, ptab + (size_t)np * n_cols);
+        c->dpar = dp;
+        c->np_pad = (np + 1) & ~1;
         std::vector<float> dpf(dp.begin(), dp.end());
         const std::vector<double> minv = spline_second_derivative_operator();
         std::vector<float> minvf(minv.begin(), minv.end());
@@ -883,6 +1185,16 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         c->pipeline = (int)value;
         return T1D_OK;
     }
+    if (std::strcmp(name, "single_minute_kernel") == 0) {
+        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: single_minute_kernel must be 0 or 1");
+        c->single_minute_kernel = (int)value;
+        return T1D_OK;
+    }
+    if (std::strcmp(name, "integrator") == 0) {
+        if (value < -1 || value > 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: integrator must be -1 (auto), 0 (rk4) or 1 (split)");
+        c->integrator = (int)value;
+        return T1D_OK;
+    }
     if (std::strcmp(name, "scalar_params") == 0) {
         if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: scalar_params must be 0 or 1");
         c->scalar_params = (int)value;
@@ -897,6 +1209,7 @@ extern "C" int t1d_ctx_destroy(t1d_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_par64); (void)hipFree(c->d_par32); (void)hipFree(c->d_x0);
     (void)hipFree(c->d_minv64); (void)hipFree(c->d_minv32); (void)hipFree(c->d_status);
+    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32);
     delete c;
     return T1D_OK;
 }
@@ -947,6 +1260,8 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
     a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
     a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags; a.stagger = c->pipe_stagger;
+    a.prop = sizeof(T) == 8 ? (const T*)c->d_prop64 : (const T*)c->d_prop32;
+    a.prop_rows = c->split_nsub ? kPropRows(c->split_nsub) : 0; a.np_pad = c->np_pad;
     return a;
 }
 
@@ -975,8 +1290,18 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     // measured at 1 Mi envs, fp64: VGPR parameters + sub-system-wise RK4 cost ~75 us + 78 us/minute, the LDS-
     // parameter kernel ~55 us + 93 us/minute: equal at one minute per launch, VGPR form ahead beyond
     const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
-    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1));
-#define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
+    if (c->integrator == 1 && !use_split(c, n_sub))
+        return fail(T1D_E_INVALID, "t1d_step: the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
+    const bool split = use_split(c, n_sub) && !c->pipeline;
+    size_t dyn = 0;
+    if (split) {
+        rc = ensure_split(c, n_sub);
+        if (rc) return rc;
+        dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
+        if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_step: split tables exceed 64 KiB of LDS (n_patients x n_sub too large); use integrator 0");
+    }
+    const int variant = c->math == 0 ? 0 : (split ? (pmode ? 4 : 5) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
+#define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
 #define T1D_LAUNCH_PIPE(V, TT) hipLaunchKernelGGL((step_pipe_kernel<V, TT>), pgrid, dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
     const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
     const char* xb = (const char*)b->x;
@@ -1004,16 +1329,48 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         if (b->dtype == T1D_F64) hipLaunchKernelGGL(refill_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s, make_args<double>(c, b, minutes, n_sub));
         else hipLaunchKernelGGL(refill_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
     }
-#define T1D_LAUNCH_FAST(V, TT) hipLaunchKernelGGL((step_kernel<V, TT, false>), grid_for(b->n), dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
-    if (split_refill) {
-        if (b->dtype == T1D_F64) { if (variant == 1) T1D_LAUNCH_FAST(1, double); else if (variant == 2) T1D_LAUNCH_FAST(2, double); else T1D_LAUNCH_FAST(3, double); }
-        else { if (variant == 1) T1D_LAUNCH_FAST(1, float); else if (variant == 2) T1D_LAUNCH_FAST(2, float); else T1D_LAUNCH_FAST(3, float); }
+    // one simulated minute per launch with the split integrator: the persistent early-store kernel
+    if (split_refill && split && minutes == 1 && c->single_minute_kernel && !(b->flags & 0xF00)) {
+        const int stride = c->np <= 32 ? 32 : 64;
+        const size_t esz1 = b->dtype == T1D_F64 ? 8 : 4;
+        const size_t dyn1 = (size_t)(DP_COUNT + kPropRows(n_sub)) * stride * esz1;
+        if (dyn1 <= 65536) {
+            const int ntiles = (int)grid_for(b->n).x;
+            int per_cu = (int)(160 * 1024 / dyn1);
+            if (per_cu > T1D_S1_WAVES) per_cu = T1D_S1_WAVES;
+            if (per_cu < 1) per_cu = 1;
+            int blocks = c->n_cu * per_cu;
+            if (c->pipe_blocks > 0) blocks = c->pipe_blocks;
+            if (blocks > ntiles) blocks = ntiles;
+            const bool reg = pmode != 0;
+#define T1D_LAUNCH_S1(R, TT, ST) hipLaunchKernelGGL((step1_kernel<R, TT, ST>), dim3(blocks), dim3(kBlock), dyn1, s, make_args<TT>(c, b, minutes, n_sub), ntiles)
+            if (b->dtype == T1D_F64) {
+                if (stride == 32) { if (reg) T1D_LAUNCH_S1(true, double, 32); else T1D_LAUNCH_S1(false, double, 32); }
+                else { if (reg) T1D_LAUNCH_S1(true, double, 64); else T1D_LAUNCH_S1(false, double, 64); }
+            } else {
+                if (stride == 32) { if (reg) T1D_LAUNCH_S1(true, float, 32); else T1D_LAUNCH_S1(false, float, 32); }
+                else { if (reg) T1D_LAUNCH_S1(true, float, 64); else T1D_LAUNCH_S1(false, float, 64); }
+            }
+#undef T1D_LAUNCH_S1
+            T1D_HIP(hipGetLastError());
+            return T1D_OK;
+        }
+    }
+#define T1D_LAUNCH_FAST(V, TT) hipLaunchKernelGGL((step_kernel<V, TT, false>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
+#define T1D_BY_VARIANT(L, TT) do { switch (variant) { case 0: L(0, TT); break; case 1: L(1, TT); break; case 2: L(2, TT); break; \
+                                                      case 3: L(3, TT); break; case 4: L(4, TT); break; default: L(5, TT); break; } } while (0)
+    if (split_refill) {          // variant != 0 here
+        if (b->dtype == T1D_F64) { switch (variant) { case 1: T1D_LAUNCH_FAST(1, double); break; case 2: T1D_LAUNCH_FAST(2, double); break; case 3: T1D_LAUNCH_FAST(3, double); break;
+                                                      case 4: T1D_LAUNCH_FAST(4, double); break; default: T1D_LAUNCH_FAST(5, double); break; } }
+        else { switch (variant) { case 1: T1D_LAUNCH_FAST(1, float); break; case 2: T1D_LAUNCH_FAST(2, float); break; case 3: T1D_LAUNCH_FAST(3, float); break;
+                                  case 4: T1D_LAUNCH_FAST(4, float); break; default: T1D_LAUNCH_FAST(5, float); break; } }
     } else if (b->dtype == T1D_F64) {
-        if (variant == 0) T1D_LAUNCH_STEP(0, double); else if (variant == 1) T1D_LAUNCH_STEP(1, double); else if (variant == 2) T1D_LAUNCH_STEP(2, double); else T1D_LAUNCH_STEP(3, double);
+        T1D_BY_VARIANT(T1D_LAUNCH_STEP, double);
     } else {
-        if (variant == 0) T1D_LAUNCH_STEP(0, float); else if (variant == 1) T1D_LAUNCH_STEP(1, float); else if (variant == 2) T1D_LAUNCH_STEP(2, float); else T1D_LAUNCH_STEP(3, float);
+        T1D_BY_VARIANT(T1D_LAUNCH_STEP, float);
     }
 #undef T1D_LAUNCH_FAST
+#undef T1D_BY_VARIANT
 #undef T1D_LAUNCH_STEP
 #undef T1D_LAUNCH_PIPE
     T1D_HIP(hipGetLastError());
@@ -1043,14 +1400,24 @@ extern "C" int t1d_rollout_pid(t1d_ctx* c, const t1d_batch* b, const t1d_pid* pi
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
     const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
-    const int variant = c->math == 0 ? 0 : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1));
-#define T1D_LAUNCH_ROLL(V, TT) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), 0, s, \
-                                                  make_args<TT>(c, b, minutes, n_sub), make_pid<TT>(pid, n_steps))
-    if (b->dtype == T1D_F64) {
-        if (variant == 0) T1D_LAUNCH_ROLL(0, double); else if (variant == 1) T1D_LAUNCH_ROLL(1, double); else if (variant == 2) T1D_LAUNCH_ROLL(2, double); else T1D_LAUNCH_ROLL(3, double);
-    } else {
-        if (variant == 0) T1D_LAUNCH_ROLL(0, float); else if (variant == 1) T1D_LAUNCH_ROLL(1, float); else if (variant == 2) T1D_LAUNCH_ROLL(2, float); else T1D_LAUNCH_ROLL(3, float);
+    if (c->integrator == 1 && !use_split(c, n_sub))
+        return fail(T1D_E_INVALID, "t1d_rollout_pid: the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
+    const bool split = use_split(c, n_sub);
+    size_t dyn = 0;
+    if (split) {
+        rc = ensure_split(c, n_sub);
+        if (rc) return rc;
+        dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
+        if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_rollout_pid: split tables exceed 64 KiB of LDS; use integrator 0");
     }
+    const int variant = c->math == 0 ? 0 : (split ? (pmode ? 4 : 5) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
+#define T1D_LAUNCH_ROLL(V, TT) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, \
+                                                  make_args<TT>(c, b, minutes, n_sub), make_pid<TT>(pid, n_steps))
+#define T1D_BY_VARIANT(L, TT) do { switch (variant) { case 0: L(0, TT); break; case 1: L(1, TT); break; case 2: L(2, TT); break; \
+                                                      case 3: L(3, TT); break; case 4: L(4, TT); break; default: L(5, TT); break; } } while (0)
+    if (b->dtype == T1D_F64) T1D_BY_VARIANT(T1D_LAUNCH_ROLL, double);
+    else T1D_BY_VARIANT(T1D_LAUNCH_ROLL, float);
+#undef T1D_BY_VARIANT
 #undef T1D_LAUNCH_ROLL
     T1D_HIP(hipGetLastError());
     return T1D_OK;

@@ -31,9 +31,12 @@ enum DevPar : int {
     DP_CCC /*5/2/d*/, DP_RATC /*f*kabs/BW*/, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2,
     DP_K1, DP_K2, DP_VM0, DP_VMX, DP_KM0, DP_M24 /*m2+m4*/, DP_M1, DP_KA1, DP_KA2, DP_VI, DP_P2U,
     DP_IB, DP_KI, DP_M130 /*m1+m30*/, DP_M2, DP_KA1KD /*ka1+kd*/, DP_KD, DP_KSC, DP_INSC /*6000/BW*/,
-    DP_VG, DP_IVI /*1/Vi*/, DP_IVG /*1/Vg*/, DP_DK /*kmax-kmin*/, DP_COUNT
+    DP_VG, DP_IVI /*1/Vi*/, DP_IVG /*1/Vg*/, DP_DK /*kmax-kmin*/,
+    // split integrator only; the four x2 weights depend on n_sub and are rewritten when it changes
+    DP_CF /*f/BW*/, DP_X2E /*exp(-kabs h)*/, DP_X2WA, DP_X2WM, DP_X2WB, DP_COUNT
 };
-constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 38 x 64 x 8 B = 19 KiB
+constexpr int DP_RK4_COUNT = DP_CF;    // rows the classical-RK4 kernels stage
+constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 43 x 64 x 8 B = 21.5 KiB
 constexpr int kBlock = 256;
 
 // parameters re-read from LDS at every use; refresh() makes the base opaque so the compiler
@@ -45,11 +48,15 @@ template <typename T> struct ParsLds {
     __device__ __forceinline__ T operator()(int idx) const { return base[idx * kMaxPatients + pid]; }
     __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(pid)); }
     __device__ __forceinline__ void pin() {}
+    __device__ __forceinline__ void pin_split() {}
 };
 // the parameters the fast-math RHS reads (everything else is per-minute set-up)
 __device__ constexpr int kRhsPars[] = {DP_KMAX, DP_DK, DP_KABS, DP_RATC, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2,
                                        DP_K1, DP_K2, DP_VM0, DP_VMX, DP_KM0, DP_M24, DP_M1, DP_KA1, DP_KA2, DP_IVI, DP_P2U,
                                        DP_IB, DP_KI, DP_M130, DP_M2, DP_KA1KD, DP_KD, DP_KSC};
+// the parameters the split integrator reads inside its loops
+__device__ constexpr int kSplitPars[] = {DP_KMAX, DP_DK, DP_RATC, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2, DP_K1, DP_K2,
+                                         DP_VM0, DP_VMX, DP_KM0, DP_KSC, DP_CF, DP_X2E, DP_X2WA, DP_X2WM, DP_X2WB};
 // parameters gathered once per lane from the (L2-resident) table and held in VGPRs for the launch
 template <typename T> struct ParsReg {
     static constexpr bool kSplitRk4 = true;    // measured: 75 us/minute split vs 79 unsplit, and far fewer spills around the loop
@@ -61,6 +68,11 @@ template <typename T> struct ParsReg {
     {
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(kRhsPars) / sizeof(int)); ++k) asm volatile("" : "+v"(v[kRhsPars[k]]));
+    }
+    __device__ __forceinline__ void pin_split()
+    {
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) asm volatile("" : "+v"(v[kSplitPars[k]]));
     }
     __device__ __forceinline__ void load(const T* __restrict__ tab, int pid)
     {
@@ -75,6 +87,7 @@ template <typename T> struct ParsScalar {
     __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
     __device__ __forceinline__ void refresh() {}
     __device__ __forceinline__ void pin() {}
+    __device__ __forceinline__ void pin_split() {}
     __device__ __forceinline__ void load(const T* __restrict__ tab, int np, int pid_uniform)
     {
 #pragma unroll
@@ -334,6 +347,151 @@ __device__ __forceinline__ void rk4_substeps_split(P& p, const MinuteIn<T>& u, T
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// ---- split integrator ------------------------------------------------------------------------------
+// The same model advanced part by part with what each part needs (oracle: t1d_o_split_minute):
+//   insulin  (x5, x9, x10, x11, x6, x7, x8) is linear with the minute's constant infusion (t1dpatient.py:
+//            176-198): exact propagator, s(tau) = Phi(tau) [s; u; 1], tau = k/ng.  The host stores the
+//            structurally non-zero entries of Phi only (PropRows below); the table is staged in LDS.
+//   gut      x0, x1 (:133-145): classical RK4, ng steps of h = 1/ng, with Q = int kgut x1 by the same
+//            quadrature; x2 (:148), whose rate kabs is the fastest of the model, in exponential form
+//            x2' = E x2 + wa F1 + wm (F2 + F3)/2 + wb F4;  R += (x2 - x2') + dQ = mass absorbed so far.
+//   glucose  (x3, x4, x12) (:151-173,201-202): classical RK4, ns = ng/2 steps, on z3 = x3 - c R with
+//            c = f/BW: the rate of appearance enters through x3 = z3 + c R(tau) at the stage times, where
+//            X = x6 and XL = x8 come from the propagator.
+// Accuracy against a tight solve equals RK4(n_sub = ng) on all 13 states (both are limited by the
+// gastric-emptying tanh); arithmetic is ~60 % of it, and far fewer values are alive at once.
+//
+// Propagator rows, ng blocks of 14 then a tail of 21 (kPropRows(ng) = 14 ng + 21):
+//   block k = 1..ng at (k-1)*14:  x6(k/ng) <- [x6, x5, x9, x10, x11, u, 1],  x8(k/ng) <- [x8, x7, x5, x9, x10, x11, u]
+//   tail (tau = 1) at 14 ng:      x5 <- [x5, x9, x10, x11, u], x9 <- same, x10 <- [x10, u], x11 <- [x10, x11, u],
+//                                 x7 <- [x7, x5, x9, x10, x11, u]
+__host__ __device__ constexpr int kPropRows(int ng) { return 14 * ng + 21; }
+
+struct NoProp { static constexpr bool kSplit = false; };
+// compact LDS tables with a compile-time row stride (persistent single-minute kernel): every read is one
+// ds_read_b64 with an immediate offset
+template <typename T, int STRIDE> struct ParsLdsS {
+    static constexpr bool kSplitRk4 = false;
+    const T* base; int pid;
+    __device__ __forceinline__ T operator()(int idx) const { return base[idx * STRIDE + pid]; }
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(pid)); }
+    __device__ __forceinline__ void pin() {}
+    __device__ __forceinline__ void pin_split() {}
+};
+template <typename T, int STRIDE> struct PropLdsS {
+    static constexpr bool kSplit = true;
+    const T* base; int pid;
+    __device__ __forceinline__ T operator()(int r) const { return base[r * STRIDE + pid]; }
+};
+// table in LDS, [rows][stride] with the patient index fastest (different patients -> different banks)
+template <typename T> struct PropLds {
+    static constexpr bool kSplit = true;
+    const T* base; int stride; int pid;
+    __device__ __forceinline__ T operator()(int r) const { return base[r * stride + pid]; }
+};
+
+template <typename T, typename P, typename PR>
+__device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int ng)
+{
+    const int ns = ng >> 1;
+    const T h = T(1) / T(ng), hh = T(0.5) * h, h6 = h / T(6);
+    const T H = h + h, H6 = H / T(6);                 // glucose step; its half step is h
+    const T s5 = x[5], s6 = x[6], s7 = x[7], s8 = x[8], s9 = x[9], s10 = x[10], s11 = x[11], ui = u.ins;
+    T g0 = x[0], g1 = x[1], x2 = x[2], R = T(0);      // R: mass that left x2 through kabs since the minute began
+    T z3 = x[3], x4 = x[4], x12 = x[12];
+    T cRa = T(0), cDa = p(DP_RATC) * x2, x6a = s6, x8a = s8;      // c R, c R', X, XL at the start of the glucose step
+    const T elo = sizeof(T) == 8 ? T(-745) : T(-80), ehi = sizeof(T) == 8 ? T(350) : T(40);
+
+    auto kgutF = [&](T q0, T q1) -> T {                // kgut(x0 + x1) * x1                       (:126-145)
+        const T qsto = q0 + q1;
+        const T a2 = t_max(t_min(u.aa * (qsto - u.bD), ehi), elo);
+        const T c2 = t_max(t_min(u.cc * (qsto - u.dD), ehi), elo);
+        const T ea = exp_core(a2), ec = exp_core(c2);
+        const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
+        return kgut * q1;
+    };
+    auto gut_step = [&]() {
+        p.refresh();
+        const T kmax = p(DP_KMAX);
+        const T F1 = kgutF(g0, g1);
+        const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;
+        T y0 = g0 + hh * a0, y1 = g1 + hh * a1;
+        const T F2 = kgutF(y0, y1);
+        const T b0 = u.d_mg - kmax * y0, b1 = kmax * y0 - F2;
+        y0 = g0 + hh * b0; y1 = g1 + hh * b1;
+        const T F3 = kgutF(y0, y1);
+        const T c0 = u.d_mg - kmax * y0, c1 = kmax * y0 - F3;
+        y0 = g0 + h * c0; y1 = g1 + h * c1;
+        const T F4 = kgutF(y0, y1);
+        const T e0 = u.d_mg - kmax * y0, e1 = kmax * y0 - F4;
+        const T F23 = F2 + F3;
+        g0 += h6 * (a0 + T(2) * (b0 + c0) + e0);
+        g1 += h6 * (a1 + T(2) * (b1 + c1) + e1);
+        const T x2n = p(DP_X2E) * x2 + p(DP_X2WA) * F1 + p(DP_X2WM) * (T(0.5) * F23) + p(DP_X2WB) * F4;
+        R += (x2 - x2n) + h6 * (F1 + T(2) * F23 + F4);     // d(x2 + R) = kgut x1 dt
+        x2 = x2n;
+    };
+    auto x6_at = [&](int r) -> T {
+        return pr(r) * s6 + pr(r + 1) * s5 + pr(r + 2) * s9 + pr(r + 3) * s10 + pr(r + 4) * s11 + pr(r + 5) * ui + pr(r + 6);
+    };
+    auto x8_at = [&](int r) -> T {
+        return pr(r) * s8 + pr(r + 1) * s7 + pr(r + 2) * s5 + pr(r + 3) * s9 + pr(r + 4) * s10 + pr(r + 5) * s11 + pr(r + 6) * ui;
+    };
+    auto glucose = [&](T y3, T y4, T y12, T cR, T cD, T X, T XL, T& d3, T& d4, T& d12) {
+        p.refresh();
+        const T x3 = y3 + cR;
+        const T egp = p(DP_KP1) - p(DP_KP2) * x3 - p(DP_KP3) * XL;                             // :153
+        const T et = p(DP_KE1) * t_max(x3 - p(DP_KE2), T(0));                                  // :158-161
+        const T k1x3 = p(DP_K1) * x3, k2x4 = p(DP_K2) * y4;
+        const T f3 = t_max(egp, T(0)) - p(DP_FSNC) - et - k1x3 + k2x4;                         // :165 without Rat
+        d3 = (x3 >= T(0)) ? f3 : -cD;                                                          // :167
+        const T vmt = p(DP_VM0) + p(DP_VMX) * X;                                               // :169
+        const T uid = fdiv(vmt * y4, p(DP_KM0) + y4);                                          // :171
+        const T f4 = -uid + k1x3 - k2x4;                                                       // :172
+        d4 = (y4 >= T(0)) ? f4 : T(0);                                                         // :173
+        const T ksc = p(DP_KSC);
+        const T f12 = -ksc * y12 + ksc * x3;                                                   // :201
+        d12 = (y12 >= T(0)) ? f12 : T(0);                                                      // :202
+    };
+
+    for (int s = 0; s < ns; ++s) {
+        gut_step();
+        const T cRm = p(DP_CF) * R, cDm = p(DP_RATC) * x2;
+        gut_step();
+        const T cRb = p(DP_CF) * R, cDb = p(DP_RATC) * x2;
+        // one propagator row at a time: 28 table reads in flight at once would cost 56 VGPRs
+        const int r = s * 28;
+        __builtin_amdgcn_sched_barrier(0);
+        const T x6m = x6_at(r);
+        __builtin_amdgcn_sched_barrier(0);
+        const T x8m = x8_at(r + 7);
+        __builtin_amdgcn_sched_barrier(0);
+        const T x6b = x6_at(r + 14);
+        __builtin_amdgcn_sched_barrier(0);
+        const T x8b = x8_at(r + 21);
+        __builtin_amdgcn_sched_barrier(0);
+        T k3, k4, k12, a3, a4, a12;
+        glucose(z3, x4, x12, cRa, cDa, x6a, x8a, k3, k4, k12);
+        a3 = k3; a4 = k4; a12 = k12;
+        glucose(z3 + h * k3, x4 + h * k4, x12 + h * k12, cRm, cDm, x6m, x8m, k3, k4, k12);
+        a3 += T(2) * k3; a4 += T(2) * k4; a12 += T(2) * k12;
+        glucose(z3 + h * k3, x4 + h * k4, x12 + h * k12, cRm, cDm, x6m, x8m, k3, k4, k12);
+        a3 += T(2) * k3; a4 += T(2) * k4; a12 += T(2) * k12;
+        glucose(z3 + H * k3, x4 + H * k4, x12 + H * k12, cRb, cDb, x6b, x8b, k3, k4, k12);
+        z3 += H6 * (a3 + k3); x4 += H6 * (a4 + k4); x12 += H6 * (a12 + k12);
+        cRa = cRb; cDa = cDb; x6a = x6b; x8a = x8b;
+    }
+    const int t0 = 14 * ng;
+    x[0] = g0; x[1] = g1; x[2] = x2;
+    x[3] = z3 + cRa; x[4] = x4; x[12] = x12;
+    x[6] = x6a; x[8] = x8a;
+    x[5] = pr(t0) * s5 + pr(t0 + 1) * s9 + pr(t0 + 2) * s10 + pr(t0 + 3) * s11 + pr(t0 + 4) * ui;
+    x[9] = pr(t0 + 5) * s5 + pr(t0 + 6) * s9 + pr(t0 + 7) * s10 + pr(t0 + 8) * s11 + pr(t0 + 9) * ui;
+    x[10] = pr(t0 + 10) * s10 + pr(t0 + 11) * ui;
+    x[11] = pr(t0 + 12) * s10 + pr(t0 + 13) * s11 + pr(t0 + 14) * ui;
+    x[7] = pr(t0 + 15) * s7 + pr(t0 + 16) * s5 + pr(t0 + 17) * s9 + pr(t0 + 18) * s10 + pr(t0 + 19) * s11 + pr(t0 + 20) * ui;
 }
 
 template <int MATH, typename T, typename P>

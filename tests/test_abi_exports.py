@@ -80,3 +80,42 @@ def test_batch_struct_layout_matches_header():
             if m and part.strip():
                 pf.append(m[0])
     assert pf == [f[0] for f in _lib.Pid._fields_]
+
+
+@pytest.mark.parametrize("n_sub", [2, 4, 6, 8])
+def test_split_tables_match_independent_matrix_exponential(n_sub):
+    """t1d_split_tables (host-only: the library's own scaling-and-squaring exp and series weights) against
+    the oracle's tables (scipy.linalg.expm + Gauss-Legendre quadrature) for all 30 patients; entries the
+    sparse device layout leaves out must be structural zeros of the dense propagator."""
+    from simglucose_amd import _lib, params
+    from oracle import t1d_oracle as O
+    L = _lib.lib()
+    names, tab = params.patient_table()
+    dense = O.split_tables(tab, n_sub)
+    dp = C.POINTER(C.c_double)
+    rows = 14 * n_sub + 21
+    c6, c8 = [4, 0, 1, 2, 3, 7, 8], [6, 5, 0, 1, 2, 3, 7]
+    c5, c7 = [0, 1, 2, 3, 7], [5, 0, 1, 2, 3, 7]
+    for ip in range(len(names)):
+        out = np.zeros(rows + 4)
+        row = np.ascontiguousarray(tab[ip])
+        assert L.t1d_split_tables(row.ctypes.data_as(dp), 45, n_sub, out.ctypes.data_as(dp), len(out)) == 0
+        phi = dense[ip, :n_sub * 63].reshape(n_sub, 7, 9)
+        want = np.zeros(rows)
+        used = np.zeros((7, 9), bool)
+        for k in range(n_sub):
+            want[k * 14:k * 14 + 7] = phi[k, 4, c6]
+            want[k * 14 + 7:k * 14 + 14] = phi[k, 6, c8]
+        t = 14 * n_sub
+        want[t:t + 5] = phi[-1, 0, c5]; want[t + 5:t + 10] = phi[-1, 1, c5]
+        want[t + 10:t + 12] = phi[-1, 2, [2, 7]]; want[t + 12:t + 15] = phi[-1, 3, [2, 3, 7]]
+        want[t + 15:t + 21] = phi[-1, 5, c7]
+        for r, cols in ((4, c6), (6, c8), (0, c5), (1, c5), (2, [2, 7]), (3, [2, 3, 7]), (5, c7)):
+            used[r, cols] = True
+        assert np.abs(phi[:, ~used]).max() < 1e-14            # what the layout drops is zero
+        scale = np.maximum(np.abs(want), 1e-3)
+        assert (np.abs(out[:rows] - want) / scale).max() < 1e-12, names[ip]
+        assert np.abs(out[rows:] - dense[ip, n_sub * 63:]).max() < 1e-14, names[ip]
+    bad = np.zeros(10)
+    assert L.t1d_split_tables(np.ascontiguousarray(tab[0]).ctypes.data_as(dp), 45, 3, bad.ctypes.data_as(dp), 10) != 0
+    assert L.t1d_split_tables(np.ascontiguousarray(tab[0]).ctypes.data_as(dp), 45, 4, bad.ctypes.data_as(dp), 10) != 0

@@ -53,7 +53,7 @@ def test_meal_table_equals_dense_cho_and_oracle(sensor):
             e.set_meals(mt, ma)
         e.reset()
         envs.append(e)
-    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="rk4", n_sub=4)
+    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="split", n_sub=4)     # the default integrator at even n_sub
     orc.reset()
     b = _basal(pid)
     for k in range(nstep):
@@ -83,7 +83,7 @@ def test_philox_noise_replays_through_host_normals_and_oracle():
     assert stats.kstest(zz[:, ::7].ravel(), "norm").pvalue > 1e-4
     assert abs(np.corrcoef(zz[0], zz[1])[0, 1]) < 0.06
     e2 = _mk(patient=pid, sensor="Dexcom", noise="host", normals=z, n_sub=2)
-    orc = O.OracleEnv(pid, sensor="Dexcom", normals=zz, integrator="rk4", n_sub=2)
+    orc = O.OracleEnv(pid, sensor="Dexcom", normals=zz, integrator="split", n_sub=2)
     o1, o2, r = e1.reset().clone(), e2.reset().clone(), orc.reset()
     assert torch.equal(o1, o2)
     assert np.abs(o1.cpu().numpy() - r["cgm"]).max() < 1e-9
@@ -258,6 +258,7 @@ def test_pipelined_kernel_matches_tile_kernel_and_oracle(dtype, params):
     for pipe in (1, 0):
         e = _mk(patient=pid, sensor="Dexcom", dtype=dt, noise="host", normals=z, n_sub=4)
         e.set_option("pipeline", pipe); e.set_option("pipe_blocks", 3)
+        e.set_option("integrator", 0)            # the persistent kernel integrates with classical RK4 only
         e.set_option("scalar_params", 1 if params == "scalar" else 0)
         e.set_option("params_mode", 1 if params == "reg" else 0)
         mt, ma = sb.tables_from_minute_lists(lists, device=e.device, dtype=dt)
@@ -279,8 +280,10 @@ def test_pipelined_kernel_matches_tile_kernel_and_oracle(dtype, params):
             e.step(torch.as_tensor(a, dtype=dt, device=e.device), torch.as_tensor(bol, dtype=dt, device=e.device))
         r = orc.step(a, bol, dense[3 * k:3 * k + 3])
         for key in ("cgm", "bg", "reward", "meal", "insulin", "x", "planned", "last_cgm", "prev_cgm"):
-            d = float((getattr(envs[0], key).double() - getattr(envs[1], key).double()).abs().max())
-            assert d < (1e-9 if dtype == "f64" else 1e-3), (k, key, d)
+            v0, v1 = getattr(envs[0], key).double(), getattr(envs[1], key).double()
+            d = float((v0 - v1).abs().max())
+            # fp32: a few ulp of the largest value (stomach contents reach ~3e4 mg, ulp 4e-3)
+            assert d < (1e-9 if dtype == "f64" else max(1e-3, 1e-6 * float(v0.abs().max()))), (k, key, d)
         assert torch.equal(envs[0].t, envs[1].t) and torch.equal(envs[0].meta, envs[1].meta) and torch.equal(envs[0].done, envs[1].done)
         assert np.abs(envs[0].bg.double().cpu().numpy() - r["bg"]).max() < tol
         assert np.abs(envs[0].cgm.double().cpu().numpy() - r["cgm"]).max() < tol

@@ -15,7 +15,13 @@ TOL_ORACLE = 1e-8
 TOL_SCIPY = 1e-3
 
 
-VARIANTS = ("ref", "lds", "reg", "reg_inline", "scalar", "pipe_lds", "pipe_reg", "pipe_scalar")
+VARIANTS = ("ref", "lds", "reg", "reg_inline", "scalar", "pipe_lds", "pipe_reg", "pipe_scalar", "split_reg", "split_lds",
+            "split_inline")
+
+
+def _integ(variant):
+    """oracle integrator that restates what this kernel variant does"""
+    return "split" if variant.startswith("split") else "rk4"
 
 
 def _env(variant="scalar", **kw):
@@ -28,8 +34,9 @@ def _env(variant="scalar", **kw):
     env.set_option("math", 0 if variant == "ref" else 1)
     env.set_option("scalar_params", 1 if variant in ("scalar", "pipe_scalar") else 0)
     env.set_option("pipeline", 1 if variant.startswith("pipe") else 0)
-    env.set_option("params_mode", 1 if variant in ("reg", "reg_inline", "pipe_reg") else 0)
-    env.set_option("split_refill", 0 if variant == "reg_inline" else 1)       # 0: noise-block refill inlined in the step kernel
+    env.set_option("params_mode", 1 if variant in ("reg", "reg_inline", "pipe_reg", "split_reg", "split_inline") else 0)
+    env.set_option("split_refill", 0 if variant in ("reg_inline", "split_inline") else 1)   # 0: noise-block refill inlined in the step kernel
+    env.set_option("integrator", 1 if variant.startswith("split") else 0)
     return env
 
 
@@ -61,7 +68,7 @@ def test_env_step_vs_oracle_and_golden(golden, sensor, seed, pname, variant):
 
     env = _env(variant, patient=[pname] * 3, sensor=sensor, noise="host", normals=np.repeat(z[:, None], 3, 1), n_sub=4)
     assert env.wave_uniform
-    orc = O.OracleEnv([names.index(pname)], sensor=sensor, normals=z[:, None], integrator="rk4", n_sub=4)
+    orc = O.OracleEnv([names.index(pname)], sensor=sensor, normals=z[:, None], integrator=_integ(variant), n_sub=4)
     obs0 = env.reset().cpu().numpy()
     r0 = orc.reset()
     assert abs(obs0[0] - r0["cgm"][0]) < 1e-10
@@ -137,7 +144,7 @@ def test_config2_1024_replicas_vs_scipy(golden, variant):
     assert worst < TOL_SCIPY, worst
 
 
-@pytest.mark.parametrize("variant", ("ref", "lds", "reg", "reg_inline", "pipe_lds", "pipe_reg"))
+@pytest.mark.parametrize("variant", ("ref", "lds", "reg", "reg_inline", "pipe_lds", "pipe_reg", "split_reg", "split_lds"))
 def test_all_30_patients_24h_vs_scipy_and_oracle(golden, variant):
     """G2 for every virtual patient in one batch (heterogeneous patient ids in one wave)."""
     import torch
@@ -162,7 +169,7 @@ def test_all_30_patients_24h_vs_scipy_and_oracle(golden, variant):
         for ip in range(30):
             # pump with a 1e-9 pmol increment still rounds: feed the oracle the quantised value
             q = O.pump(g["basal"][ip] * g["action_mult"][t], 1e-9, 0.0, 1e9)
-            orc[ip].step(cho[t], q, integrator="rk4", n_sub=4)
+            orc[ip].step(cho[t], q, integrator=_integ(variant), n_sub=4)
         if t % 10 == 9:
             bg = info["bg"].cpu().numpy()
             worst_s = max(worst_s, np.abs(bg - g["gsub_default"][:, t + 1]).max())

@@ -41,12 +41,13 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--sensor", default="Navigator")
     ap.add_argument("--n-sub", type=int, default=4)
+    ap.add_argument("--variants", default="reg,g_split_reg,split_lds,split_reg")
     a = ap.parse_args()
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     cfgs = []
     for layout in ("mod30", "run64"):
         env, pool = make(a.envs, layout, dt, a.sensor, a.n_sub)
-        for var in ("lds", "reg", "pipe_lds", "pipe_reg"):
+        for var in a.variants.split(","):
             if var in ("scalar", "pipe_scalar") and not env.wave_uniform:
                 continue
             cfgs.append((layout, var, env, pool))
@@ -55,7 +56,9 @@ def main():
         for layout, var, env, pool in cfgs:
             env.set_option("math", 0 if var == "ref" else 1)
             env.set_option("scalar_params", 1 if var in ("scalar", "pipe_scalar") else 0)
-            env.set_option("params_mode", 1 if var in ("reg", "pipe_reg") else (2 if var == "loc" else 0))
+            env.set_option("params_mode", 1 if var.endswith("reg") else 0)
+            env.set_option("integrator", 1 if "split" in var else 0)
+            env.set_option("single_minute_kernel", 0 if var.startswith("g_") else 1)      # g_: generic one-tile-per-block kernel
             env.set_option("pipeline", 1 if var.startswith("pipe") else 0)
             for k in range(3):
                 env.step(pool[k % 4])
