@@ -36,6 +36,7 @@ template <typename T> struct KArgs {
     const double* x0tab;    // [13][np]
     const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
     int* status;
+    long long* trace;       // T1D_S1_TRACE builds only: phase timestamps of the first blocks' waves
     SensorC<T> sen; PumpC<T> pump;
     int np, S, n_meals, n_normals, minutes, n_sub, flags, stagger, prop_rows, np_pad;
 };
@@ -60,9 +61,19 @@ template <typename U> __device__ __forceinline__ U* row(U* base, int64_t n, int 
 // row whose index may differ between lanes (meal cursor, noise block): ordinary per-lane address
 template <typename U> __device__ __forceinline__ U* rowv(U* base, int64_t n, int k) { return base + (int64_t)k * n; }
 // element i of a uniform-base array through an explicit 32-bit BYTE offset (i < 2^28 by contract)
-template <typename U> __device__ __forceinline__ U& at(U* base, unsigned i)
+// The access goes through an explicit address_space(1) pointer: row() hides a pointer's provenance, and a
+// pointer the compiler cannot trace back to a kernel argument is accessed with FLAT instructions, which
+// count on BOTH vmcnt and lgkmcnt -- every LDS wait of the integration loop would then also wait for them.
+template <typename U> struct GRef {
+    __attribute__((address_space(1))) U* p;
+    __device__ __forceinline__ operator U() const { return *p; }
+    __device__ __forceinline__ const GRef& operator=(U v) const { *p = v; return *this; }
+};
+template <typename U> __device__ __forceinline__ GRef<U> at(U* base, unsigned i)
 {
-    return *(U*)((char*)base + (unsigned)(i * (unsigned)sizeof(U)));
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) U gU;
+    return GRef<U>{(gU*)((gchar*)base + (unsigned)(i * (unsigned)sizeof(U)))};
 }
 
 // env state held in registers across the minutes of a launch
@@ -419,24 +430,66 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
 #ifndef T1D_S1_WAVES
 #define T1D_S1_WAVES 3
 #endif
+#ifndef T1D_S1_TRACE
+#define T1D_S1_TRACE 0
+#endif
+#ifndef T1D_S1_ROTATE_PRIO
+#define T1D_S1_ROTATE_PRIO 1
+#endif
+#if T1D_S1_TRACE
+// tuning builds: drain every counter and stamp the wall clock (100 MHz) at phase boundaries
+#define S1_MARK(m) do { __builtin_amdgcn_s_waitcnt(0x0070); if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + (m)] = (long long)wall_clock64(); } while (0)
+#else
+#define S1_MARK(m) do { } while (0)
+#endif
+constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a CU: T1D_S1_WAVES waves on each of its 4 SIMDs
 template <bool REG, typename T, int STRIDE>
-__global__ __launch_bounds__(kBlock, T1D_S1_WAVES) void step1_kernel(const KArgs<T> a, int ntiles)
+__global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
-    for (int j = threadIdx.x; j < DP_COUNT * STRIDE; j += kBlock) {
+    __shared__ int queue;
+    for (int j = threadIdx.x; j < DP_COUNT * STRIDE; j += kS1Threads) {
         const int r = j / STRIDE, c = j % STRIDE;
         ldp[j] = c < a.np ? a.dpar[r * kMaxPatients + c] : T(0);
     }
-    for (int j = threadIdx.x; j < a.prop_rows * STRIDE; j += kBlock) {
+    for (int j = threadIdx.x; j < a.prop_rows * STRIDE; j += kS1Threads) {
         const int r = j / STRIDE, c = j % STRIDE;
         lpr[j] = c < a.np ? a.prop[r * a.np_pad + c] : T(0);
     }
+    if (threadIdx.x == 0) queue = 0;
     __syncthreads();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const unsigned i = (unsigned)tile * kBlock + threadIdx.x;
+    // This workgroup owns a contiguous run of 64-env chunks; its waves draw them from a queue in LDS.  The
+    // SIMD issues oldest-wave-first, so with a fixed share per wave the first wave of a SIMD would race ahead
+    // and the last would finish alone (measured: 66 vs 93 us); with the queue the fast wave simply takes more.
+    const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int first = (int)blockIdx.x * per_block;
+    const int count = nchunks - first < per_block ? nchunks - first : per_block;
+    const unsigned lane = threadIdx.x & 63u;
+#if T1D_S1_TRACE
+    long long* tr = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (kS1Threads / 64) + threadIdx.x / 64) * 64 : nullptr;
+    int tk = -1;
+#endif
+    for (int it = 0;; ++it) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&queue, 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= count) break;                              // wave-uniform
+        const unsigned i = (unsigned)(first + c) * 64u + lane;
         __builtin_assume(i < (1u << 28));
-        if ((int64_t)i >= a.n) break;
+        if ((int64_t)i >= a.n) continue;
+#if T1D_S1_TRACE
+        ++tk;
+#endif
+#if T1D_S1_ROTATE_PRIO
+        // rotate the issue priority among the waves of a SIMD (waves w, w + 4, w + 8 of the workgroup) chunk by chunk
+        switch ((unsigned)(it + (int)(threadIdx.x >> 8)) % 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(2); break;
+        }
+#endif
+        S1_MARK(0);
         const uint32_t meta = at(a.meta, i);
         const uint32_t pid = T1D_META_PID(meta);
         Env<T> e;
@@ -450,6 +503,7 @@ __global__ __launch_bounds__(kBlock, T1D_S1_WAVES) void step1_kernel(const KArgs
         e.cursor = (int)T1D_META_CURSOR(meta);
         const T basal = at(a.basal, i);
         const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+        S1_MARK(1);
         T q_basal, q_bolus;
         if (a.flags & T1D_BATCH_NO_PUMP) {
             q_basal = basal; q_bolus = a.bolus ? bolus : T(0);
@@ -469,6 +523,7 @@ __global__ __launch_bounds__(kBlock, T1D_S1_WAVES) void step1_kernel(const KArgs
         at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
         if (a.meal) at(a.meal, i) = meal;
         if (a.insulin) at(a.insulin, i) = insulin;
+        S1_MARK(2);
         {
             PropLdsS<T, STRIDE> pr{lpr, (int)pid};
             if (REG) {
@@ -476,11 +531,12 @@ __global__ __launch_bounds__(kBlock, T1D_S1_WAVES) void step1_kernel(const KArgs
 #pragma unroll
                 for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
                 p.pin_split();
-                split_minute(p, pr, u, e.x, a.n_sub);
+                if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub);
             } else {
-                split_minute(pl, pr, u, e.x, a.n_sub);
+                if (!(a.flags & 0x800)) split_minute(pl, pr, u, e.x, a.n_sub);
             }
         }
+        S1_MARK(3);
 #pragma unroll
         for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
         // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
@@ -488,6 +544,7 @@ __global__ __launch_bounds__(kBlock, T1D_S1_WAVES) void step1_kernel(const KArgs
         for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.pts, a.n, 22 + k), i);
         T last_cgm = at(a.last_cgm, i);
         const T prev_cgm = at(a.prev_cgm, i);
+        S1_MARK(4);
         bool due;
         const T noise = measure_noise<false>(a, i, e, due);       // e.t is still the minute's start: sample for t + 1
         const T rp = prev_risk<1>(a, prev_cgm);
@@ -512,6 +569,10 @@ __global__ __launch_bounds__(kBlock, T1D_S1_WAVES) void step1_kernel(const KArgs
             if (a.risk) at(a.risk, i) = r;
         }
         if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+#if T1D_S1_TRACE
+        if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + 5] = (long long)wall_clock64();    // epilogue computed, stores issued
+#endif
+        S1_MARK(6);
     }
 }
 
@@ -877,6 +938,7 @@ struct t1d_ctx {
     int split_nsub = 0;      // n_sub the split tables on the device were built for (0 = none yet)
     int np_pad = 0;
     double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
+    long long* d_trace = nullptr;    // T1D_S1_TRACE builds
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
 };
@@ -1062,6 +1124,9 @@ static bool use_split(const t1d_ctx* c, int n_sub)
     return can && c->integrator != 0;
 }
 
+#if T1D_S1_TRACE
+extern "C" int t1d_debug_trace(t1d_ctx* c, long long* out) { return hipMemcpy(out, c->d_trace, 96 * 4 * 64 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+#endif
 extern "C" int t1d_abi_version(void) { return T1D_ABI_VERSION; }
 extern "C" const char* t1d_last_error(void) { return g_err.c_str(); }
 
@@ -1136,6 +1201,10 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
         if (e == hipSuccess) e = up((void**)&c->d_x0, x0.data(), x0.size() * 8);
         if (e == hipSuccess) e = up((void**)&c->d_minv64, minv.data(), minv.size() * 8);
         if (e == hipSuccess) e = up((void**)&c->d_minv32, minvf.data(), minvf.size() * 4);
+#if T1D_S1_TRACE
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_trace, 96 * 4 * 64 * sizeof(long long));
+        if (e == hipSuccess) e = hipMemset(c->d_trace, 0, 96 * 4 * 64 * sizeof(long long));
+#endif
         if (e == hipSuccess) e = hipMalloc((void**)&c->d_status, sizeof(int));
         if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(int));
         if (e != hipSuccess) {
@@ -1209,7 +1278,7 @@ extern "C" int t1d_ctx_destroy(t1d_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_par64); (void)hipFree(c->d_par32); (void)hipFree(c->d_x0);
     (void)hipFree(c->d_minv64); (void)hipFree(c->d_minv32); (void)hipFree(c->d_status);
-    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32);
+    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); (void)hipFree(c->d_trace);
     delete c;
     return T1D_OK;
 }
@@ -1252,7 +1321,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.dpar = sizeof(T) == 8 ? (const T*)c->d_par64 : (const T*)c->d_par32;
     a.x0tab = c->d_x0;
     a.minv = sizeof(T) == 8 ? (const T*)c->d_minv64 : (const T*)c->d_minv32;
-    a.status = c->d_status;
+    a.status = c->d_status; a.trace = c->d_trace;
     a.sen.pacf = (T)c->sensor[0]; a.sen.gamma = (T)c->sensor[1]; a.sen.lambda = (T)c->sensor[2];
     a.sen.delta = (T)c->sensor[3]; a.sen.xi = (T)c->sensor[4]; a.sen.st = (int)c->sensor[5];
     a.sen.vmin = (T)c->sensor[6]; a.sen.vmax = (T)c->sensor[7];
@@ -1330,20 +1399,16 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         else hipLaunchKernelGGL(refill_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
     }
     // one simulated minute per launch with the split integrator: the persistent early-store kernel
-    if (split_refill && split && minutes == 1 && c->single_minute_kernel && !(b->flags & 0xF00)) {
+    if (split_refill && split && minutes == 1 && c->single_minute_kernel && !(b->flags & 0x600)) {
         const int stride = c->np <= 32 ? 32 : 64;
         const size_t esz1 = b->dtype == T1D_F64 ? 8 : 4;
         const size_t dyn1 = (size_t)(DP_COUNT + kPropRows(n_sub)) * stride * esz1;
         if (dyn1 <= 65536) {
-            const int ntiles = (int)grid_for(b->n).x;
-            int per_cu = (int)(160 * 1024 / dyn1);
-            if (per_cu > T1D_S1_WAVES) per_cu = T1D_S1_WAVES;
-            if (per_cu < 1) per_cu = 1;
-            int blocks = c->n_cu * per_cu;
-            if (c->pipe_blocks > 0) blocks = c->pipe_blocks;
-            if (blocks > ntiles) blocks = ntiles;
+            const int nchunks = (int)((b->n + 63) / 64);
+            int blocks = c->pipe_blocks > 0 ? c->pipe_blocks : c->n_cu;       // one workgroup of 4 x T1D_S1_WAVES waves per CU
+            if (blocks > nchunks) blocks = nchunks;
             const bool reg = pmode != 0;
-#define T1D_LAUNCH_S1(R, TT, ST) hipLaunchKernelGGL((step1_kernel<R, TT, ST>), dim3(blocks), dim3(kBlock), dyn1, s, make_args<TT>(c, b, minutes, n_sub), ntiles)
+#define T1D_LAUNCH_S1(R, TT, ST) hipLaunchKernelGGL((step1_kernel<R, TT, ST>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
             if (b->dtype == T1D_F64) {
                 if (stride == 32) { if (reg) T1D_LAUNCH_S1(true, double, 32); else T1D_LAUNCH_S1(false, double, 32); }
                 else { if (reg) T1D_LAUNCH_S1(true, double, 64); else T1D_LAUNCH_S1(false, double, 64); }

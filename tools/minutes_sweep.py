@@ -6,9 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.ab_step import make  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-for var in ("reg", "lds"):
+for var in ("reg", "split_reg", "split_lds"):
     env, pool = make(n, "run64", torch.float64, "Navigator", 4)
-    env.set_option("scalar_params", 0); env.set_option("params_mode", 1 if var == "reg" else 0)
+    env.set_option("scalar_params", 0); env.set_option("params_mode", 1 if var.endswith("reg") else 0)
+    env.set_option("integrator", 1 if var.startswith("split") else 0)
     for minutes in (1, 2, 4, 8, 16):
         for k in range(3):
             env.step(pool[k % 4], minutes=minutes)
