@@ -5,7 +5,9 @@ One "step" = one pass of the hot path over the batch = ONE kernel launch advanci
 one simulated minute (1-min dt: Navigator-class sensor, sample_time = 1).  Workload at N = 1:
 BASELINE.json configs[3]'s batch -- 1 048 576 concurrent envs, patient = i mod 30, random-action
 policy (basal = U(0,2) x the patient's steady-state basal, from a pool of pre-generated action
-tensors resident in HBM), per-env random meal tables, fp64, RK4 n_sub = 4, Philox CGM noise.
+tensors resident in HBM), per-env random meal tables, fp64, n_sub = 4 sub-steps per minute (the library's default
+"split" fixed-step integrator: exact insulin propagator + RK4 gut/glucose, same error vs SciPy as RK4(4) on all
+13 states -- DESIGN.md section 3; `--integrator rk4` times classical RK4), Philox CGM noise.
 With --gpus N each rank owns its own 1 Mi envs (weak scaling; independent episodes, no data-path
 collective); value = all ranks' env-steps / max-over-ranks wall time.
 
@@ -28,13 +30,13 @@ ALGO_BYTES = {"f64": 352, "f32": 184}       # algorithmic HBM 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(n_envs, steps, n_sub, sensor):
+def cpu_baseline(n_envs, steps, n_sub, sensor, integ="split"):
     """The CPU oracle (oracle/t1d_oracle.c, a from-scratch port of the reference path with the same
     RK4 integrator) timed on one host core over a bounded sample of the same workload."""
     from oracle import t1d_oracle as O
     rs = np.random.RandomState(0)
     pid = np.arange(n_envs) % 30
-    env = O.OracleEnv(pid, sensor=sensor, normals=rs.randn(64, n_envs), integrator="rk4", n_sub=n_sub)
+    env = O.OracleEnv(pid, sensor=sensor, normals=rs.randn(64, n_envs), integrator=integ, n_sub=n_sub)
     env.reset()
     names, tab = O.patient_table()
     basal0 = tab[pid, O.IDX["u2ss"]] * tab[pid, O.IDX["BW"]] / 6000.0
@@ -49,7 +51,7 @@ def cpu_baseline(n_envs, steps, n_sub, sensor):
         env.step(acts[k % 4], None, cho)
     dt = time.perf_counter() - t0
     return {"value": n_envs * steps * int(env.sample_time) / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d steps, RK4 n_sub=%d, fp64, 1 thread, %.1f s" % (n_envs, steps, n_sub, dt)}
+            "sample": "%d envs x %d steps, %s integrator n_sub=%d (same scheme as the kernel), fp64, 1 thread, %.1f s" % (n_envs, steps, integ, n_sub, dt)}
 
 
 def main():
@@ -61,6 +63,7 @@ def main():
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--n-sub", type=int, default=4)
     ap.add_argument("--sensor", default="Navigator")
+    ap.add_argument("--integrator", choices=("auto", "rk4", "split"), default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
@@ -91,6 +94,8 @@ def main():
     pid = np.arange(n, dtype=np.int64) % 30
     env = BatchedT1DSimEnv(patient=pid, sensor=a.sensor, dtype=dt, device=dev, n_sub=a.n_sub, seed=1234,
                            env_offset=rank * n, noise="philox", extra_outputs=False)
+    env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
+    integ = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else "split"
     days = 1 + (a.steps + a.warmup) * env.minutes_per_step // 1440
     mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=0, seed=1000 + rank, device=dev, dtype=dt)
     env.set_meals(mt, ma)
@@ -132,7 +137,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
                     tj = json.load(f)
-                if (tj["envs"], tj["dtype"], tj["n_sub"], tj["minutes"]) == (n, a.dtype, a.n_sub, minutes):
+                if (tj["envs"], tj["dtype"], tj["n_sub"], tj["minutes"], tj.get("integrator", "rk4")) == (n, a.dtype, a.n_sub, minutes, integ):
                     traffic = tj["traffic_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 traffic = None
@@ -144,17 +149,17 @@ def main():
             "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "configs[3]: %d envs per GPU, patient=i mod 30, random-action policy, "
-                                   "random meal tables, %s sensor (sample_time %d min), RK4 n_sub=%d, Philox CGM noise"
-                                   % (n, a.sensor, minutes, a.n_sub),
-                       "envs_per_gpu": n, "n_sub": a.n_sub, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
+                                   "random meal tables, %s sensor (sample_time %d min), %s integrator n_sub=%d, Philox CGM noise"
+                                   % (n, a.sensor, minutes, integ, a.n_sub),
+                       "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "t1d::step_kernel<3, %s, false>" % ("double" if a.dtype == "f64" else "float"),
+                         "traffic": traffic, "kernel": ("t1d::step1_kernel<true, %s, 32>" if integ == "split" and minutes == 1 else "t1d::step_kernel<%d, %s, false>" % (4 if integ == "split" else 3, "%s")) % ("double" if a.dtype == "f64" else "float"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
         }
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_envs, a.cpu_steps, a.n_sub, a.sensor)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_envs, a.cpu_steps, a.n_sub, a.sensor, integ)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -12,6 +12,9 @@
 #ifndef T1D_WAVES
 #define T1D_WAVES 2
 #endif
+#ifndef T1D_ROW_RECOMPUTE
+#define T1D_ROW_RECOMPUTE 1
+#endif
 
 #include <climits>
 #include <cmath>
@@ -54,9 +57,18 @@ template <typename T> struct PidArgs {
 // `global_* v_off, s[base:base+1]` form and no per-row 64-bit VGPR address survives from load to store.
 template <typename U> __device__ __forceinline__ U* row(U* base, int64_t n, int k)
 {
+#if T1D_ROW_RECOMPUTE
+    // the (volatile) asm keeps the row offset in scalar registers AND stops the compiler from hoisting dozens of
+    // loop-invariant row pointers out of a tile loop, where they would overflow the SGPR file and be parked in
+    // VGPR lanes (v_writelane / v_readlane around every access): a few scalar ops per access are cheaper
+    int kk = k;
+    asm volatile("" : "+s"(kk));
+    return base + (int64_t)kk * n;
+#else
     U* p = base + (int64_t)k * n;
     asm volatile("" : "+s"(p));
     return p;
+#endif
 }
 // row whose index may differ between lanes (meal cursor, noise block): ordinary per-lane address
 template <typename U> __device__ __forceinline__ U* rowv(U* base, int64_t n, int k) { return base + (int64_t)k * n; }
@@ -446,6 +458,9 @@ constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a C
 template <bool REG, typename T, int STRIDE>
 __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
+    // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
+    // prev_cgm and the 26 noise rows; rows 1, 2 of the t buffer are meta and next_meal.  Deriving them from two
+    // base pointers instead of reading ten more kernel arguments keeps the scalar registers from spilling.
     T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
     __shared__ int queue;
@@ -490,14 +505,14 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         }
 #endif
         S1_MARK(0);
-        const uint32_t meta = at(a.meta, i);
+        const uint32_t meta = at(row(a.t, a.n, 1), i);
         const uint32_t pid = T1D_META_PID(meta);
         Env<T> e;
 #pragma unroll
         for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
-        e.planned = at(a.planned, i); e.lq = at(a.last_qsto, i); e.lf = at(a.last_food, i);
+        e.planned = at(row(a.x, a.n, 13), i); e.lq = at(row(a.x, a.n, 14), i); e.lf = at(row(a.x, a.n, 15), i);
         e.t = at(a.t, i);
-        e.next_meal = a.next_meal ? at(a.next_meal, i) : 0;
+        e.next_meal = at(row(a.t, a.n, 2), i);
         e.next_meal_loaded = e.next_meal;
         e.eating = (meta & T1D_META_EATING) != 0;
         e.cursor = (int)T1D_META_CURSOR(meta);
@@ -517,10 +532,10 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
         MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
         // bookkeeping is final for this minute: store it now
-        at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
+        at(row(a.x, a.n, 13), i) = e.planned; at(row(a.x, a.n, 14), i) = e.lq; at(row(a.x, a.n, 15), i) = e.lf;
         at(a.t, i) = e.t + 1;
-        if (a.next_meal && e.next_meal != e.next_meal_loaded) at(a.next_meal, i) = e.next_meal;
-        at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+        if (e.next_meal != e.next_meal_loaded) at(row(a.t, a.n, 2), i) = e.next_meal;
+        at(row(a.t, a.n, 1), i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
         if (a.meal) at(a.meal, i) = meal;
         if (a.insulin) at(a.insulin, i) = insulin;
         S1_MARK(2);
@@ -541,9 +556,9 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
         // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.pts, a.n, 22 + k), i);
-        T last_cgm = at(a.last_cgm, i);
-        const T prev_cgm = at(a.prev_cgm, i);
+        for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.x, a.n, 40 + k), i);
+        T last_cgm = at(row(a.x, a.n, 16), i);
+        const T prev_cgm = at(row(a.x, a.n, 17), i);
         S1_MARK(4);
         bool due;
         const T noise = measure_noise<false>(a, i, e, due);       // e.t is still the minute's start: sample for t + 1
@@ -554,12 +569,12 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
             c = c > a.sen.vmin ? c : a.sen.vmin;
             c = c < a.sen.vmax ? c : a.sen.vmax;
             last_cgm = c;
-            at(a.last_cgm, i) = c;
+            at(row(a.x, a.n, 16), i) = c;
         }
         T l, h, r, rc = T(0);
         if (!(a.flags & 0x100)) risk_index1<1>(last_cgm, l, h, rc);
         at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
-        at(a.prev_cgm, i) = last_cgm;
+        at(row(a.x, a.n, 17), i) = last_cgm;
         at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
         at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
         if (a.lbgi || a.hbgi || a.risk) {
@@ -1399,7 +1414,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         else hipLaunchKernelGGL(refill_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
     }
     // one simulated minute per launch with the split integrator: the persistent early-store kernel
-    if (split_refill && split && minutes == 1 && c->single_minute_kernel && !(b->flags & 0x600)) {
+    if (split_refill && split && minutes == 1 && c->single_minute_kernel && packed && !(b->flags & 0x600)) {
         const int stride = c->np <= 32 ? 32 : 64;
         const size_t esz1 = b->dtype == T1D_F64 ? 8 : 4;
         const size_t dyn1 = (size_t)(DP_COUNT + kPropRows(n_sub)) * stride * esz1;
