@@ -151,6 +151,19 @@ typedef struct t1d_pid {
     int32_t* n_high;          /* [n] += (bg > 180) per step */
 } t1d_pid;
 
+/* BBController (controller/basal_bolus_ctrller.py:15-80) for closed-loop roll-outs: per-env constants the
+ * host takes from vpatient_params.csv / Quest.csv (unknown patients: CR 1/15, CF 1/50, basal 1.43*57/6000,
+ * :61-64) and one word of state. */
+typedef struct t1d_bb {
+    double target;            /* 140 mg/dL (:21) */
+    const void* basal;        /* [n] u2ss * BW / 6000 U/min (:64) */
+    const void* cr;           /* [n] Quest.csv CR, g/U */
+    const void* cf;           /* [n] Quest.csv CF, mg/dL/U */
+    void* prev_meal;          /* [n] state: info['meal'] of the previous step, g/min (0 after reset) */
+    /* optional per-env accumulators over the roll-out (NULL to skip), as in t1d_pid */
+    void* sum_risk; void* min_bg; void* max_bg; int32_t* n_low; int32_t* n_high;
+} t1d_bb;
+
 int t1d_abi_version(void);
 const char* t1d_last_error(void);
 
@@ -192,6 +205,14 @@ int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
  * insulin propagator Phi(k/n_sub) (layout in simglucose_amd/csrc/t1d_device.hpp) followed by the four
  * weights E, wa, wm, wb of the exponential gut update; out_len >= 14 n_sub + 25.  What t1d_step
  * uploads; exposed so that the tables can be checked against an independent matrix exponential. */
+/* SimObj.simulate (sim_engine.py:29-39) with BBController for n_steps env.steps in ONE launch: per step
+ * basal = bb.basal; bolus = (prev_meal*sample_time/CR + (CGM > 150)*(CGM - target)/CF) / sample_time if
+ * prev_meal > 0 else 0 (:66-79), where CGM is the previous step's observation (batch.cgm on entry) and
+ * prev_meal the previous step's mean announced CHO; then the same step as t1d_step with meals from the
+ * meal tables.  Outputs/state as t1d_rollout_pid; bb.prev_meal is updated. */
+int t1d_rollout_bb(t1d_ctx* ctx, const t1d_batch* batch, const t1d_bb* bb, int n_steps, int minutes,
+                   int n_sub, void* stream);
+
 int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
 
 /* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after

@@ -245,6 +245,45 @@ class BatchedT1DSimEnv:
                                                self.minutes_per_step, self.n_sub, self._stream()))
         return pid_state
 
+    def bb_constants(self):
+        """Per-env BBController constants (basal_bolus_ctrller.py:54-64): basal = u2ss*BW/6000 U/min, CR and CF from
+        Quest.csv; patients Quest.csv does not list get the reference's 'Average' row (CR 1/15, CF 1/50,
+        u2ss 1.43, BW 57).  -> dict of tensors [n]."""
+        quest = params.quest_table()
+        basal = np.empty(len(self.names)); cr = np.empty(len(self.names)); cf = np.empty(len(self.names))
+        for k, name in enumerate(self.names):
+            if name in quest:
+                cr[k], cf[k] = quest[name][0], quest[name][1]
+                basal[k] = params.basal_rate(self.table[k])
+            else:
+                cr[k], cf[k], basal[k] = 1.0 / 15.0, 1.0 / 50.0, 1.43 * 57.0 / 6000.0
+        mk = lambda v: torch.as_tensor(v[self.patient_idx], dtype=self.dtype, device=self.device).contiguous()
+        return {"basal": mk(basal), "cr": mk(cr), "cf": mk(cf)}
+
+    def rollout_bb(self, n_steps, target=140.0, bb_state=None, stats=None):
+        """n_steps closed-loop BBController steps in one launch (SimObj.simulate with BBController: policy from
+        the previous observation and the previous step's announced meal, then env.step).  bb_state: dict with
+        basal, cr, cf (see bb_constants) and prev_meal [n] (created if None; prev_meal = 0 right after reset).
+        Meals come from the meal tables (set_meals).  stats as in rollout_pid."""
+        if bb_state is None:
+            bb_state = self.bb_constants()
+            bb_state["prev_meal"] = torch.zeros(self.n, dtype=self.dtype, device=self.device)
+        p = _lib.Bb()
+        p.target = float(target)
+        for k in ("basal", "cr", "cf", "prev_meal"):
+            setattr(p, k, bb_state[k].data_ptr())
+        stats = stats or {}
+        for k in ("sum_risk", "min_bg", "max_bg", "n_low", "n_high"):
+            setattr(p, k, stats[k].data_ptr() if k in stats else None)
+        self._b.cho = None
+        self._b.flags = self._flags0
+        if self._clock is not None:
+            self._clock += int(n_steps) * self.minutes_per_step
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.t1d_rollout_bb(self._ctx, C.byref(self._b), C.byref(p), int(n_steps),
+                                              self.minutes_per_step, self.n_sub, self._stream()))
+        return bb_state
+
     def philox_normals(self, n_draws, draw0=0, episode=1):
         """The normals the kernels draw in Philox mode -> float64 [n_draws, n] (for replay tests)."""
         out = torch.empty(n_draws, self.n, dtype=torch.float64, device=self.device)

@@ -48,6 +48,8 @@ template <typename T> struct PidArgs {
     T P, I, D, target;
     T* integ; T* prev; T* sum_risk; T* min_bg; T* max_bg; int32_t* n_low; int32_t* n_high;
     int n_steps;
+    int kind;               // 0 = PIDController, 1 = BBController
+    const T* bb_basal; const T* bb_cr; const T* bb_cf; T* bb_prev_meal;
 };
 
 // Row k of a [K][n] array as a wave-uniform base pointer: the lane index i then rides in ONE 32-bit
@@ -779,7 +781,10 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
 {
     constexpr int MATH = VariantMath<VARIANT>::value;
     T obs = at(a.cgm, i);
-    T integ = at(c.integ, i), prev = at(c.prev, i);
+    const bool bb = c.kind == 1;
+    T integ = T(0), prev = T(0), bb_basal = T(0), bb_cr = T(1), bb_cf = T(1), prev_meal = T(0);
+    if (bb) { bb_basal = at(c.bb_basal, i); bb_cr = at(c.bb_cr, i); bb_cf = at(c.bb_cf, i); prev_meal = at(c.bb_prev_meal, i); }
+    else { integ = at(c.integ, i); prev = at(c.prev, i); }
     T sum_risk = c.sum_risk ? at(c.sum_risk, i) : T(0);
     T min_bg = c.min_bg ? at(c.min_bg, i) : T(0), max_bg = c.max_bg ? at(c.max_bg, i) : T(0);
     int n_low = c.n_low ? at(c.n_low, i) : 0, n_high = c.n_high ? at(c.n_high, i) : 0;
@@ -787,12 +792,23 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
     StepOut<T> o{obs, T(0), T(0), T(0)};
     T pre_prev_cgm = e.prev_cgm;
     for (int s = 0; s < c.n_steps; ++s) {
-        // PIDController.policy (pid_ctrller.py:17-36)
-        const T u = c.P * (obs - c.target) + c.I * integ + c.D * (obs - prev) / st;
-        prev = obs;
-        integ += (obs - c.target) * st;
-        o = step_body<MATH, T, P, NoHook, false, true, PR>(a, p, i, e, u, T(0), true, NoHook(), pr);
+        T u, bolus = T(0);
+        if (bb) {
+            // BBController._bb_policy (basal_bolus_ctrller.py:64-79)
+            u = bb_basal;
+            if (prev_meal > T(0)) {
+                const T corr = obs > T(150) ? (obs - c.target) / bb_cf : T(0);
+                bolus = ((prev_meal * st) / bb_cr + corr) / st;
+            }
+        } else {
+            // PIDController.policy (pid_ctrller.py:17-36)
+            u = c.P * (obs - c.target) + c.I * integ + c.D * (obs - prev) / st;
+            prev = obs;
+            integ += (obs - c.target) * st;
+        }
+        o = step_body<MATH, T, P, NoHook, false, true, PR>(a, p, i, e, u, bolus, true, NoHook(), pr);
         obs = o.cgm;
+        prev_meal = o.meal;
         pre_prev_cgm = e.prev_cgm;
         e.prev_cgm = o.cgm;                      // CGM history advances every step
         if (c.sum_risk) { T l, h, r; risk_index1<MATH>(o.bg, l, h, r); sum_risk += r; }
@@ -803,7 +819,8 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
     e.prev_cgm = pre_prev_cgm;                   // the last step's reward is formed from it
     write_outputs<MATH>(a, i, e, o, prev_risk<MATH>(a, pre_prev_cgm));
     store_env(a, i, pid, e);
-    at(c.integ, i) = integ; at(c.prev, i) = prev;
+    if (bb) at(c.bb_prev_meal, i) = prev_meal;
+    else { at(c.integ, i) = integ; at(c.prev, i) = prev; }
     if (c.sum_risk) at(c.sum_risk, i) = sum_risk;
     if (c.min_bg) at(c.min_bg, i) = min_bg;
     if (c.max_bg) at(c.max_bg, i) = max_bg;
@@ -1465,42 +1482,73 @@ static PidArgs<T> make_pid(const t1d_pid* p, int n_steps)
     c.integ = (T*)p->integ; c.prev = (T*)p->prev; c.sum_risk = (T*)p->sum_risk;
     c.min_bg = (T*)p->min_bg; c.max_bg = (T*)p->max_bg; c.n_low = p->n_low; c.n_high = p->n_high;
     c.n_steps = n_steps;
+    c.kind = 0; c.bb_basal = nullptr; c.bb_cr = nullptr; c.bb_cf = nullptr; c.bb_prev_meal = nullptr;
     return c;
 }
 
-extern "C" int t1d_rollout_pid(t1d_ctx* c, const t1d_batch* b, const t1d_pid* pid, int n_steps, int minutes,
-                               int n_sub, void* stream)
+template <typename T>
+static PidArgs<T> make_bb(const t1d_bb* p, int n_steps)
 {
-    int rc = check_batch("t1d_rollout_pid", c, b, false);
+    PidArgs<T> c;
+    c.P = c.I = c.D = T(0); c.target = (T)p->target;
+    c.integ = nullptr; c.prev = nullptr; c.sum_risk = (T*)p->sum_risk;
+    c.min_bg = (T*)p->min_bg; c.max_bg = (T*)p->max_bg; c.n_low = p->n_low; c.n_high = p->n_high;
+    c.n_steps = n_steps;
+    c.kind = 1; c.bb_basal = (const T*)p->basal; c.bb_cr = (const T*)p->cr; c.bb_cf = (const T*)p->cf; c.bb_prev_meal = (T*)p->prev_meal;
+    return c;
+}
+
+template <typename MK64, typename MK32>
+static int launch_rollout(const char* who, t1d_ctx* c, const t1d_batch* b, int n_steps, int minutes, int n_sub, void* stream,
+                          MK64 mk64, MK32 mk32)
+{
+    int rc = check_batch(who, c, b, false);
     if (rc) return rc;
-    if (!pid || !pid->integ || !pid->prev) return fail(T1D_E_INVALID, "t1d_rollout_pid: pid state is NULL");
-    if (b->cho) return fail(T1D_E_INVALID, "t1d_rollout_pid: dense cho is not supported, use the meal table");
-    if (n_steps < 1) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_steps < 1");
-    if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_rollout_pid: minutes out of range");
-    if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_rollout_pid: n_sub out of range");
+    if (b->cho) return fail(T1D_E_INVALID, std::string(who) + ": dense cho is not supported, use the meal table");
+    if (n_steps < 1) return fail(T1D_E_INVALID, std::string(who) + ": n_steps < 1");
+    if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, std::string(who) + ": minutes out of range");
+    if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, std::string(who) + ": n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
     const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
     if (c->integrator == 1 && !use_split(c, n_sub))
-        return fail(T1D_E_INVALID, "t1d_rollout_pid: the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
+        return fail(T1D_E_INVALID, std::string(who) + ": the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
     const bool split = use_split(c, n_sub);
     size_t dyn = 0;
     if (split) {
         rc = ensure_split(c, n_sub);
         if (rc) return rc;
         dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
-        if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_rollout_pid: split tables exceed 64 KiB of LDS; use integrator 0");
+        if (dyn > 65536) return fail(T1D_E_INVALID, std::string(who) + ": split tables exceed 64 KiB of LDS; use integrator 0");
     }
     const int variant = c->math == 0 ? 0 : (split ? (pmode ? 4 : 5) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
-#define T1D_LAUNCH_ROLL(V, TT) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, \
-                                                  make_args<TT>(c, b, minutes, n_sub), make_pid<TT>(pid, n_steps))
-#define T1D_BY_VARIANT(L, TT) do { switch (variant) { case 0: L(0, TT); break; case 1: L(1, TT); break; case 2: L(2, TT); break; \
-                                                      case 3: L(3, TT); break; case 4: L(4, TT); break; default: L(5, TT); break; } } while (0)
-    if (b->dtype == T1D_F64) T1D_BY_VARIANT(T1D_LAUNCH_ROLL, double);
-    else T1D_BY_VARIANT(T1D_LAUNCH_ROLL, float);
+#define T1D_LAUNCH_ROLL(V, TT, MK) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, \
+                                                      make_args<TT>(c, b, minutes, n_sub), MK())
+#define T1D_BY_VARIANT(TT, MK) do { switch (variant) { case 0: T1D_LAUNCH_ROLL(0, TT, MK); break; case 1: T1D_LAUNCH_ROLL(1, TT, MK); break; \
+                                                       case 2: T1D_LAUNCH_ROLL(2, TT, MK); break; case 3: T1D_LAUNCH_ROLL(3, TT, MK); break; \
+                                                       case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; default: T1D_LAUNCH_ROLL(5, TT, MK); break; } } while (0)
+    if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, mk64);
+    else T1D_BY_VARIANT(float, mk32);
 #undef T1D_BY_VARIANT
 #undef T1D_LAUNCH_ROLL
     T1D_HIP(hipGetLastError());
     return T1D_OK;
+}
+
+extern "C" int t1d_rollout_pid(t1d_ctx* c, const t1d_batch* b, const t1d_pid* pid, int n_steps, int minutes,
+                               int n_sub, void* stream)
+{
+    if (!pid || !pid->integ || !pid->prev) return fail(T1D_E_INVALID, "t1d_rollout_pid: pid state is NULL");
+    return launch_rollout("t1d_rollout_pid", c, b, n_steps, minutes, n_sub, stream,
+                          [&] { return make_pid<double>(pid, n_steps); }, [&] { return make_pid<float>(pid, n_steps); });
+}
+
+extern "C" int t1d_rollout_bb(t1d_ctx* c, const t1d_batch* b, const t1d_bb* bb, int n_steps, int minutes,
+                              int n_sub, void* stream)
+{
+    if (!bb || !bb->basal || !bb->cr || !bb->cf || !bb->prev_meal)
+        return fail(T1D_E_INVALID, "t1d_rollout_bb: basal / cr / cf / prev_meal must be set");
+    return launch_rollout("t1d_rollout_bb", c, b, n_steps, minutes, n_sub, stream,
+                          [&] { return make_bb<double>(bb, n_steps); }, [&] { return make_bb<float>(bb, n_steps); });
 }
 
 extern "C" int t1d_philox_normals(t1d_ctx* c, uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,

@@ -80,6 +80,15 @@ def test_batch_struct_layout_matches_header():
             if m and part.strip():
                 pf.append(m[0])
     assert pf == [f[0] for f in _lib.Pid._fields_]
+    body = src[src.index("typedef struct t1d_bb {"):src.index("} t1d_bb;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    bf = []
+    for stmt in body.replace("typedef struct t1d_bb {", "").split(";"):
+        for part in stmt.split(","):
+            m = re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())
+            if m and part.strip():
+                bf.append(m[0])
+    assert bf == [f[0] for f in _lib.Bb._fields_]
 
 
 @pytest.mark.parametrize("n_sub", [2, 4, 6, 8])

@@ -173,6 +173,66 @@ def test_rollout_pid_matches_step_by_step_and_oracle(golden):
     assert ea.sync() == 0 and eb.sync() == 0
 
 
+def test_rollout_bb_config1_matches_reference_host_loop_and_oracle(golden):
+    """BASELINE config 1 on the device: adult#001 + BBController + RandomScenario(seed 1), Dexcom seed 1, 24 h
+    (fixture G6, recorded from the reference).  t1d_rollout_bb (K steps per launch) must equal K x (host
+    BBController + t1d_step), follow the oracle's restatement of the same integrator to 1e-8, and stay
+    within 1e-3 mg/dL of the reference's SciPy trace; other patients (heterogeneous batch) against the oracle."""
+    import csv, os, torch
+    from simglucose_amd import scenario_batch as sb, params
+    from oracle import t1d_oracle as O
+    K, st = 480, 3
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g6_config1_adult001_bb.csv"), newline="") as f:
+        rows = list(csv.DictReader(f))
+    ref_bg = np.array([float(r["BG"]) for r in rows]); ref_cgm = np.array([float(r["CGM"]) for r in rows])
+    acts = golden("g6_config1_actions.npz")["actions"]
+    names = ["adult#001", "adolescent#003", "child#008", "adult#010"]
+    z = np.random.RandomState(1).randn(1 + 10 * (2 + (K * st) // 150))
+    cho = O.random_scenario_cho(1, 0, K * st)
+    lst = [(int(m), float(cho[m])) for m in np.nonzero(cho)[0]]
+    n = len(names) * 16
+    pname = [names[i // 16] for i in range(n)]
+    envs = []
+    for _ in range(2):
+        e = _mk(patient=pname, sensor="Dexcom", noise="host", normals=np.repeat(z[:, None], n, 1), n_sub=4)
+        mt, ma = sb.tables_from_minute_lists([lst] * n, device=e.device)
+        e.set_meals(mt, ma)
+        e.reset()
+        envs.append(e)
+    ea, eb = envs
+    # (a) host BBController (basal_bolus_ctrller.py:34-80) around t1d_step
+    c = ea.bb_constants()
+    obs, meal = ea.cgm.clone(), torch.zeros(n, dtype=torch.float64, device=ea.device)
+    bg_a, cgm_a, act_a = [], [], []
+    for k in range(K):
+        bolus = torch.where(meal > 0, ((meal * st) / c["cr"] + (obs > 150) * (obs - 140.0) / c["cf"]) / st, torch.zeros_like(meal))
+        act_a.append((float(c["basal"][0]), float(bolus[0])))
+        ea.step(c["basal"], bolus)
+        obs, meal = ea.cgm.clone(), ea.meal.clone()
+        bg_a.append(ea.bg.clone()); cgm_a.append(ea.cgm.clone())
+    assert np.abs(np.array(act_a) - acts).max() < 1e-6                       # same controls as the reference run
+    bg_a = torch.stack(bg_a).cpu().numpy(); cgm_a = torch.stack(cgm_a).cpu().numpy()
+    assert np.abs(bg_a[:, 0] - ref_bg[1:]).max() < 1e-3 and np.abs(cgm_a[:, 0] - ref_cgm[1:]).max() < 1e-3
+    # (b) the same in-kernel, in chunks of different lengths
+    stt = None
+    stats = {"n_high": torch.zeros(n, dtype=torch.int32, device=eb.device),
+             "max_bg": torch.zeros(n, dtype=torch.float64, device=eb.device)}
+    for chunk in (1, 9, 170, 300):
+        stt = eb.rollout_bb(chunk, bb_state=stt, stats=stats)
+    for k in ("x", "t", "cgm", "bg", "last_cgm", "prev_cgm", "reward", "planned", "meal", "insulin"):
+        assert torch.allclose(getattr(ea, k).double(), getattr(eb, k).double(), rtol=0, atol=1e-9), k
+    assert torch.allclose(stt["prev_meal"], meal, atol=1e-12)
+    assert np.array_equal(stats["n_high"].cpu().numpy(), (bg_a > 180).sum(0))
+    assert np.abs(stats["max_bg"].cpu().numpy() - bg_a.max(0)).max() < 1e-9
+    # (c) the oracle's closed loop with the same scheme, every patient of the batch
+    for j, nm in enumerate(names):
+        hist, a = O.closed_loop(nm, "Dexcom", 1, 1, K, lambda cgm, info, nm=nm: O.bb_policy(nm, info["meal"], cgm, info["sample_time"]),
+                                integrator="split", n_sub=4)
+        assert np.abs(bg_a[:, 16 * j] - hist["BG"][1:]).max() < 1e-8, nm
+        assert np.abs(cgm_a[:, 16 * j] - hist["CGM"][1:]).max() < 1e-8, nm
+    assert ea.sync() == 0 and eb.sync() == 0
+
+
 def test_fp32_tracks_fp64():
     """fp32 variant (BASELINE configs 3/5): stays within 0.05 mg/dL of fp64 over 12 h with meals."""
     import torch

@@ -62,4 +62,15 @@ for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
                                           "bg_mean": float(env.bg.double().mean())}
     del env
     torch.cuda.empty_cache()
+# config 1 at scale: 30 patients x 2 048 seeds, in-kernel BBController, 24 h (480 Dexcom steps) in one launch
+n = 61440
+env, _ = make(n, torch.float64, "Dexcom", days=2)
+env.rollout_bb(10)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+env.rollout_bb(480)
+torch.cuda.synchronize(); wall = time.perf_counter() - t0
+out["config1_bb_61440_f64_24h"] = {"seconds_for_24_h": wall, "env_steps_per_s": n * 1440 / wall,
+                                   "status": env.sync(raise_on_status=False), "bg_mean": float(env.bg.double().mean())}
+del env
+torch.cuda.empty_cache()
 print(json.dumps(out, indent=1))
