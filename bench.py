@@ -97,7 +97,7 @@ def main():
     env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
     integ = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else "split"
     days = 1 + (a.steps + a.warmup) * env.minutes_per_step // 1440
-    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=0, seed=1000 + rank, device=dev, dtype=dt)
+    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=0, seed=1000, device=dev, dtype=dt, env_offset=rank * n)
     env.set_meals(mt, ma)
     basal0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, dtype=dt, device=dev)
     g = torch.Generator(device=dev); g.manual_seed(7 + rank)

@@ -213,6 +213,16 @@ int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 int t1d_rollout_bb(t1d_ctx* ctx, const t1d_batch* batch, const t1d_bb* bb, int n_steps, int minutes,
                    int n_sub, void* stream);
 
+/* RandomScenario.create_scenario (simulation/scenario_gen.py:33-60) for n envs on the device: fills per-env
+ * meal tables meal_time int32 [6 (days + 1)][n] (minutes since the episode start, ascending, unused =
+ * INT32_MAX) and meal_amt [6 (days + 1)][n] (grams, dtype T1D_F64/F32) covering `days` days of an episode
+ * that starts at start_minute_of_day[i] (device int32 [n]) or, if that is NULL, at start_scalar for every
+ * env.  Statistical counterpart of the reference's numpy stream (Philox, subsequence = env_offset + i);
+ * exact replays of a reference scenario go through explicit tables instead.  No ctx needed. */
+int t1d_random_meals(int hip_device, uint64_t seed, int64_t env_offset, int64_t n, int dtype, int days,
+                     const int32_t* start_minute_of_day, int start_scalar, int32_t* meal_time, void* meal_amt,
+                     void* stream);
+
 int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
 
 /* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after

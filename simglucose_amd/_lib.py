@@ -21,7 +21,7 @@ META_EATING = 0x100
 
 EXPORTS = ("t1d_abi_version", "t1d_last_error", "t1d_ctx_create", "t1d_ctx_set_option", "t1d_ctx_destroy", "t1d_reset",
            "t1d_step", "t1d_rollout_pid", "t1d_philox_normals", "t1d_sync", "t1d_split_tables",
-           "t1d_rollout_bb")
+           "t1d_rollout_bb", "t1d_random_meals")
 
 
 class T1DError(RuntimeError):
@@ -99,6 +99,7 @@ def lib():
     L.t1d_step.argtypes = [vp, C.POINTER(Batch), C.c_int, C.c_int, vp]
     L.t1d_rollout_pid.argtypes = [vp, C.POINTER(Batch), C.POINTER(Pid), C.c_int, C.c_int, C.c_int, vp]
     L.t1d_rollout_bb.argtypes = [vp, C.POINTER(Batch), C.POINTER(Bb), C.c_int, C.c_int, C.c_int, vp]
+    L.t1d_random_meals.argtypes = [C.c_int, u64, i64, i64, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
     L.t1d_philox_normals.argtypes = [vp, u64, i64, i64, u32, i32, i32, vp, vp]
     L.t1d_sync.argtypes = [vp, vp, C.POINTER(i32)]
     L.t1d_split_tables.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int]

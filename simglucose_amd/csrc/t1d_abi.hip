@@ -941,6 +941,55 @@ __global__ void philox_normals_kernel(uint64_t seed, int64_t env_offset, int64_t
     }
 }
 
+
+// ---- RandomScenario.create_scenario for a whole batch (simulation/scenario_gen.py:33-60) ----------------
+// One lane = one env: for each calendar day the episode touches, six candidate meals with presence
+// probabilities (.95,.3,.95,.3,.95,.3), truncated-normal times of day (inverse-CDF sampling between the
+// window bounds, rounded to the minute) and max(round(N(mu, sigma)), 0) grams.  The windows are contiguous
+// and increasing, so a day's meals come out in time order; a meal landing on the minute of the one before it
+// (window boundary) is dropped, as the reference's dict-by-time scenario keeps one entry per minute.
+// Statistical counterpart of the reference (numpy's MT19937 stream is not reproduced); Philox subsequence =
+// global env id, two blocks per candidate meal, in a key domain of its own (seed ^ kScenarioKey).
+struct MealSlots {
+    double prob[6], lb[6], ub[6], mu[6], sd[6], amu[6], asd[6], cdf_a[6], cdf_w[6];
+};
+constexpr uint64_t kScenarioKey = 0x5ce9a7105ce9a710ull;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void random_meals_kernel(uint64_t seed, int64_t env_offset, int64_t n, int days,
+                                                              const int32_t* start_tab, int start_scalar,
+                                                              int32_t* meal_time, T* meal_amt, MealSlots ms)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int rows = 6 * (days + 1);
+    const int start = start_tab ? start_tab[i] : start_scalar;
+    const uint64_t gid = (uint64_t)(env_offset + i);
+    int w = 0, last = -1;
+    for (int day = 0; day <= days; ++day) {
+#pragma unroll 1
+        for (int k = 0; k < 6; ++k) {
+            rocrand_state_philox4x32_10 st;
+            rocrand_init(seed ^ kScenarioKey, gid, 8ull * (unsigned long long)(day * 6 + k), &st);
+            const double2 u = rocrand_uniform_double2(&st);           // (0, 1]
+            const double2 g = rocrand_normal_double2(&st);
+            const bool present = u.x <= ms.prob[k];                    // rand() < p            (:48)
+            double q = ms.cdf_a[k] + u.y * ms.cdf_w[k];               // truncnorm.rvs          (:50-54)
+            q = fmin(fmax(2.0 * q - 1.0, -1.0 + 1e-15), 1.0 - 1e-15);
+            double tod = rint(ms.mu[k] + ms.sd[k] * 1.4142135623730951 * erfinv(q));   // np.round (:49)
+            tod = fmin(fmax(tod, ms.lb[k]), ms.ub[k]);
+            const double grams = fmax(rint(ms.amu[k] + ms.asd[k] * g.x), 0.0);          // :56-57
+            const int minute = day * 1440 + (int)tod - start;
+            if (present && minute >= 0 && minute < days * 1440 && minute != last) {
+                meal_time[(int64_t)w * n + i] = minute;
+                meal_amt[(int64_t)w * n + i] = (T)grams;
+                last = minute; ++w;
+            }
+        }
+    }
+    for (; w < rows; ++w) { meal_time[(int64_t)w * n + i] = INT_MAX; meal_amt[(int64_t)w * n + i] = T(0); }
+}
+
 } // namespace t1d
 
 // =============================================================================================
@@ -1549,6 +1598,39 @@ extern "C" int t1d_rollout_bb(t1d_ctx* c, const t1d_batch* b, const t1d_bb* bb, 
         return fail(T1D_E_INVALID, "t1d_rollout_bb: basal / cr / cf / prev_meal must be set");
     return launch_rollout("t1d_rollout_bb", c, b, n_steps, minutes, n_sub, stream,
                           [&] { return make_bb<double>(bb, n_steps); }, [&] { return make_bb<float>(bb, n_steps); });
+}
+
+extern "C" int t1d_random_meals(int hip_device, uint64_t seed, int64_t env_offset, int64_t n, int dtype, int days,
+                                const int32_t* start_minute_of_day, int start_scalar, int32_t* meal_time, void* meal_amt,
+                                void* stream)
+{
+    if (!meal_time || !meal_amt) return fail(T1D_E_INVALID, "t1d_random_meals: output pointer is NULL");
+    if (n < 1 || n > (int64_t)1 << 28) return fail(T1D_E_INVALID, "t1d_random_meals: n out of range");
+    if (days < 1 || days > 10000) return fail(T1D_E_INVALID, "t1d_random_meals: days out of range");
+    if (dtype != T1D_F64 && dtype != T1D_F32) return fail(T1D_E_INVALID, "t1d_random_meals: bad dtype");
+    if (!start_minute_of_day && (start_scalar < 0 || start_scalar >= 1440))
+        return fail(T1D_E_INVALID, "t1d_random_meals: start minute of day must be in [0, 1440)");
+    T1D_HIP(hipSetDevice(hip_device));
+    MealSlots ms;
+    const double prob[6] = {0.95, 0.3, 0.95, 0.3, 0.95, 0.3};          // scenario_gen.py:38-45
+    const double lb[6] = {5, 9, 10, 14, 16, 20}, ub[6] = {9, 10, 14, 16, 20, 23}, mu[6] = {7, 9.5, 12, 15, 18, 21.5};
+    const double sd[6] = {60, 30, 60, 30, 60, 30}, amu[6] = {45, 10, 70, 10, 80, 10}, asd[6] = {10, 5, 10, 5, 10, 5};
+    for (int k = 0; k < 6; ++k) {
+        ms.prob[k] = prob[k]; ms.lb[k] = lb[k] * 60.0; ms.ub[k] = ub[k] * 60.0; ms.mu[k] = mu[k] * 60.0;
+        ms.sd[k] = sd[k]; ms.amu[k] = amu[k]; ms.asd[k] = asd[k];
+        const double ca = 0.5 * std::erfc(-((ms.lb[k] - ms.mu[k]) / sd[k]) / std::sqrt(2.0));
+        const double cb = 0.5 * std::erfc(-((ms.ub[k] - ms.mu[k]) / sd[k]) / std::sqrt(2.0));
+        ms.cdf_a[k] = ca; ms.cdf_w[k] = cb - ca;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == T1D_F64)
+        hipLaunchKernelGGL(random_meals_kernel<double>, grid_for(n), dim3(kBlock), 0, s, seed, env_offset, n, days,
+                           start_minute_of_day, start_scalar, meal_time, (double*)meal_amt, ms);
+    else
+        hipLaunchKernelGGL(random_meals_kernel<float>, grid_for(n), dim3(kBlock), 0, s, seed, env_offset, n, days,
+                           start_minute_of_day, start_scalar, meal_time, (float*)meal_amt, ms);
+    T1D_HIP(hipGetLastError());
+    return T1D_OK;
 }
 
 extern "C" int t1d_philox_normals(t1d_ctx* c, uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,

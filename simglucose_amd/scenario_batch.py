@@ -1,6 +1,6 @@
 """Batched meal scenarios as per-env meal tables for the step kernel.
 
-``random_meal_tables`` is the vectorised, on-device statistical counterpart of the reference's
+``random_meal_tables`` is the on-device (one HIP kernel, `t1d_random_meals`) statistical counterpart of the reference's
 ``RandomScenario.create_scenario`` (``simglucose/simulation/scenario_gen.py:33-60``): per day six
 candidate meals with presence probabilities (.95,.3,.95,.3,.95,.3), truncated-normal times (minutes
 after midnight) and ``max(round(N(mu, sigma)), 0)`` grams.  It does not reproduce numpy's MT19937
@@ -9,24 +9,9 @@ it removes the per-env host loop when N is 10^6.
 
 ``tables_from_minute_lists`` packs explicit (minute, grams) lists, e.g. from CustomScenario.
 """
-import math
-
 import torch
 
 MEAL_UNUSED = 0x7FFFFFFF
-
-_PROB = (0.95, 0.3, 0.95, 0.3, 0.95, 0.3)
-_LB = (5 * 60, 9 * 60, 10 * 60, 14 * 60, 16 * 60, 20 * 60)
-_UB = (9 * 60, 10 * 60, 14 * 60, 16 * 60, 20 * 60, 23 * 60)
-_MU = (7 * 60, 9.5 * 60, 12 * 60, 15 * 60, 18 * 60, 21.5 * 60)
-_SD = (60, 30, 60, 30, 60, 30)
-_AMU = (45, 10, 70, 10, 80, 10)
-_ASD = (10, 5, 10, 5, 10, 5)
-
-
-def _phi(x):
-    return 0.5 * (1.0 + math.erf(x / math.sqrt(2.0)))
-
 
 def _finalise(times, amts):
     """sort per env by time (stable: earlier slots win ties), drop same-minute duplicates."""
@@ -40,29 +25,34 @@ def _finalise(times, amts):
     return times.to(torch.int32).contiguous(), amts.contiguous()
 
 
-def random_meal_tables(n, days=1, start_minute_of_day=0, seed=0, device="cuda:0", dtype=torch.float64):
+def random_meal_tables(n, days=1, start_minute_of_day=0, seed=0, device="cuda:0", dtype=torch.float64, env_offset=0):
     """-> (meal_time int32 [6*(days+1), n], meal_amt dtype [6*(days+1), n]) covering `days` days
-    from an episode that starts at `start_minute_of_day` (scalar or int tensor [n])."""
-    gen = torch.Generator(device=device)
-    gen.manual_seed(int(seed))
-    start = torch.as_tensor(start_minute_of_day, device=device, dtype=torch.int64).expand(n)
-    T, A = [], []
-    for day in range(days + 1):          # a non-midnight start touches days+1 calendar days
-        for k in range(6):
-            present = torch.rand(n, generator=gen, device=device, dtype=torch.float64) < _PROB[k]
-            a, b = (_LB[k] - _MU[k]) / _SD[k], (_UB[k] - _MU[k]) / _SD[k]
-            u = torch.rand(n, generator=gen, device=device, dtype=torch.float64)
-            q = _phi(a) + u * (_phi(b) - _phi(a))
-            zt = math.sqrt(2.0) * torch.erfinv((2.0 * q - 1.0).clamp(-1 + 1e-15, 1 - 1e-15))
-            tod = torch.round(_MU[k] + _SD[k] * zt).clamp(_LB[k], _UB[k]).to(torch.int64)
-            grams = torch.round(_AMU[k] + _ASD[k] * torch.randn(n, generator=gen, device=device,
-                                                                dtype=torch.float64)).clamp_min(0.0)
-            minute = day * 1440 + tod - start
-            ok = present & (minute >= 0) & (minute < days * 1440)
-            T.append(torch.where(ok, minute, torch.full_like(minute, MEAL_UNUSED)))
-            A.append(torch.where(ok, grams, torch.zeros_like(grams)))
-    times, amts = _finalise(torch.stack(T), torch.stack(A))
-    return times, amts.to(dtype)
+    from an episode that starts at `start_minute_of_day` (scalar or int tensor [n]).  One launch of
+    t1d_random_meals (include/t1d.h); env i draws from Philox subsequence env_offset + i."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.T1DError("random_meal_tables runs on the GPU (device=%s)" % device)
+    rows = 6 * (int(days) + 1)
+    mt = torch.empty(rows, n, dtype=torch.int32, device=device)
+    ma = torch.empty(rows, n, dtype=dtype, device=device)
+    start_t, start_s = None, 0
+    if isinstance(start_minute_of_day, torch.Tensor) or hasattr(start_minute_of_day, "__len__"):
+        start_t = torch.as_tensor(start_minute_of_day).to(device=device, dtype=torch.int32).contiguous()
+        if start_t.numel() != n:
+            raise ValueError("start_minute_of_day must be a scalar or have n entries")
+    else:
+        start_s = int(start_minute_of_day)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(L.t1d_random_meals(dev_index, int(seed) & 0xFFFFFFFFFFFFFFFF, int(env_offset), int(n),
+                                      0 if dtype == torch.float64 else 1, int(days),
+                                      C.c_void_p(start_t.data_ptr()) if start_t is not None else None, start_s,
+                                      C.c_void_p(mt.data_ptr()), C.c_void_p(ma.data_ptr()), stream))
+    return mt, ma
 
 
 def tables_from_minute_lists(lists, device="cuda:0", dtype=torch.float64):

@@ -233,6 +233,58 @@ def test_rollout_bb_config1_matches_reference_host_loop_and_oracle(golden):
     assert ea.sync() == 0 and eb.sync() == 0
 
 
+def test_random_meal_tables_match_reference_generator_statistics():
+    """t1d_random_meals against the reference's RandomScenario.create_scenario as restated (and
+    pinned by fixture G9) in the oracle: structure of the tables exactly, distributions per meal window within
+    sampling error of 6 000 reference days."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    from oracle import t1d_oracle as O
+    n, days = 1 << 17, 2
+    mt, ma = sb.random_meal_tables(n, days=days, start_minute_of_day=0, seed=11, device="cuda:0")
+    t, a = mt.cpu().numpy().astype(np.int64), ma.cpu().numpy()
+    assert t.shape == (6 * (days + 1), n)
+    used = t != 0x7FFFFFFF
+    assert np.all(np.diff(t, axis=0)[used[1:]] > 0)                          # ascending, one meal per minute
+    assert np.all(used[:-1] | ~used[1:])                                     # unused entries only at the end
+    assert t[used].min() >= 5 * 60 and t[used].max() < days * 1440
+    assert np.all(a[~used] == 0) and np.all(a[used] >= 0) and np.all(a[used] == np.round(a[used]))
+    # deterministic; shifting env_offset shifts the streams; another seed differs
+    mt2, ma2 = sb.random_meal_tables(n, days=days, start_minute_of_day=0, seed=11, device="cuda:0")
+    assert torch.equal(mt, mt2) and torch.equal(ma, ma2)
+    mt3, _ = sb.random_meal_tables(n - 64, days=days, start_minute_of_day=0, seed=11, device="cuda:0", env_offset=64)
+    assert torch.equal(mt3, mt[:, 64:])
+    assert not torch.equal(sb.random_meal_tables(n, days=days, seed=12, device="cuda:0")[0], mt)
+    # reference sample
+    rs = np.random.RandomState(123)
+    ref_t, ref_a, ref_days = [], [], 6000
+    for _ in range(ref_days):
+        tt, aa = O.random_scenario_draw(rs)
+        ref_t += list(tt); ref_a += list(aa)
+    ref_t, ref_a = np.array(ref_t), np.array(ref_a)
+    tod, grams = t[used] % 1440, a[used]
+    lb = np.array([5, 9, 10, 14, 16, 20]) * 60; ub = np.array([9, 10, 14, 16, 20, 23]) * 60
+    assert abs(used.sum() / (n * days) - len(ref_t) / ref_days) < 5 * np.sqrt(3.75 / ref_days)      # meals per day
+    for k in range(6):
+        sel, rsel = (tod > lb[k]) & (tod < ub[k]), (ref_t > lb[k]) & (ref_t < ub[k])    # open interval: boundary minutes are ambiguous
+        f, rf = sel.sum() / (n * days), rsel.sum() / ref_days
+        assert abs(f - rf) < 5 * np.sqrt(rf * (1 - rf) / ref_days) + 1e-3, (k, f, rf)
+        for x, rx in ((tod[sel], ref_t[rsel]), (grams[sel], ref_a[rsel])):
+            se = rx.std() / np.sqrt(len(rx))
+            assert abs(x.mean() - rx.mean()) < 5 * se + 0.05, (k, x.mean(), rx.mean())
+            assert abs(x.std() - rx.std()) < 0.06 * rx.std() + 0.05, (k, x.std(), rx.std())
+    # a start at 14:00 drops the morning of day 0 and reaches into day `days`
+    mt4, _ = sb.random_meal_tables(4096, days=1, start_minute_of_day=14 * 60, seed=3, device="cuda:0")
+    t4 = mt4.cpu().numpy().astype(np.int64); u4 = t4 != 0x7FFFFFFF
+    assert t4[u4].min() >= 0 and t4[u4].max() < 1440
+    assert ((t4[u4] + 14 * 60) // 1440 == 1).any() and ((t4[u4] + 14 * 60) // 1440 == 0).any()
+    st = torch.randint(0, 1440, (4096,), dtype=torch.int32, device="cuda:0")
+    mt5, _ = sb.random_meal_tables(4096, days=1, start_minute_of_day=st, seed=3, device="cuda:0")
+    t5 = mt5.cpu().numpy().astype(np.int64); u5 = t5 != 0x7FFFFFFF
+    todd = (t5 + st.cpu().numpy()[None, :].astype(np.int64)) % 1440
+    assert todd[u5].min() >= 5 * 60 and todd[u5].max() <= 23 * 60
+
+
 def test_fp32_tracks_fp64():
     """fp32 variant (BASELINE configs 3/5): stays within 0.05 mg/dL of fp64 over 12 h with meals."""
     import torch
