@@ -1,10 +1,15 @@
 // t1d_abi.hip -- kernels and C ABI of libt1d_hip.so (gfx950 only; see include/t1d.h).
 //
 // Kernels
-//   step_kernel<T>     one launch per env.step: pump -> [meal bookkeeping -> RK4 x n_sub -> Gsub ->
-//                      CGM sample/hold] x minutes -> risk/reward/done.      (env.py:48-117)
-//   reset_kernel<T>    masked T1DSimEnv.reset().                            (env.py:119-155)
-//   rollout_pid_kernel<T>  n_steps x (PID policy + step) with state in registers.
+//   step1_kernel       the headline launch: ONE simulated minute per env.step, split integrator, one persistent
+//                      workgroup per CU whose waves draw 64-env chunks from a queue in LDS.
+//   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
+//                      n_sub sub-steps -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
+//   refill_kernel      rebuilds due 150-minute CGM noise blocks ahead of a step kernel compiled without that code.
+//   step_pipe_kernel   step_kernel made persistent with LDS-DMA prefetch (classical RK4; experiment, off by default).
+//   rollout_pid_kernel n_steps x (PID or basal-bolus policy + step) with state in registers.
+//   reset_kernel       masked T1DSimEnv.reset().                                              (env.py:119-155)
+//   random_meals_kernel  RandomScenario.create_scenario for the whole batch.          (scenario_gen.py:33-60)
 //   philox_normals_kernel  replays the Philox stream for tests.
 #include "../../include/t1d.h"
 #include "t1d_device.hpp"

@@ -233,6 +233,47 @@ def test_rollout_bb_config1_matches_reference_host_loop_and_oracle(golden):
     assert ea.sync() == 0 and eb.sync() == 0
 
 
+@pytest.mark.parametrize("n_sub", [2, 6, 8])
+def test_split_integrator_other_substep_counts_and_table_rebuild(n_sub):
+    """The split integrator at n_sub = 2, 6, 8 (tables rebuilt inside one ctx when n_sub changes) against the
+    oracle's restatement with scipy-built tables; odd n_sub falls back to classical RK4 under "auto" and is an
+    error when the split scheme is demanded."""
+    import torch
+    from simglucose_amd import _lib
+    from oracle import t1d_oracle as O
+    rs = np.random.RandomState(n_sub)
+    n = 90
+    pid = np.arange(n) % 30
+    z = rs.randn(30, n)
+    e = _mk(patient=pid, sensor="Navigator", noise="host", normals=z, n_sub=4)
+    e.reset()
+    b = _basal(pid)
+    cho = np.zeros((60, n)); cho[5] = 60.0; cho[20, ::2] = 25.0
+    e.step(torch.as_tensor(b, device=e.device), cho=cho[0:1])                 # builds the n_sub = 4 tables first
+    orc4 = O.OracleEnv(pid, sensor="Navigator", normals=z, integrator="split", n_sub=4)
+    orc4.reset(); r = orc4.step(b, None, cho[0:1])
+    assert np.abs(e.bg.cpu().numpy() - r["bg"]).max() < 1e-8
+    e.n_sub = n_sub                                                            # forces a rebuild of the tables
+    orc = O.OracleEnv(pid, sensor="Navigator", normals=z, integrator="split", n_sub=n_sub)
+    orc.reset()
+    for k in ("x", "planned", "last_qsto", "last_food", "last_cgm", "ar_e", "pts", "prev_cgm"):
+        getattr(orc, k)[...] = getattr(orc4, k)
+    orc.was_eating[:] = orc4.was_eating; orc.t[:] = orc4.t; orc.n_samples[:] = orc4.n_samples; orc.n_draws[:] = orc4.n_draws
+    for k in range(1, 60):
+        a = b * (0.5 + (k % 5) * 0.3)
+        e.step(torch.as_tensor(a, device=e.device), cho=cho[k:k + 1])
+        r = orc.step(a, None, cho[k:k + 1])
+        assert np.abs(e.bg.cpu().numpy() - r["bg"]).max() < 1e-8, k
+        assert np.abs(e.cgm.cpu().numpy() - r["cgm"]).max() < 1e-8, k
+    assert e.sync() == 0
+    e.n_sub = 3
+    e.step(torch.as_tensor(b, device=e.device), cho=cho[0:1])                 # auto: classical RK4
+    e.set_option("integrator", 1)
+    with pytest.raises(_lib.T1DError):
+        e.step(torch.as_tensor(b, device=e.device), cho=cho[0:1])
+    e.sync(raise_on_status=False)
+
+
 def test_random_meal_tables_match_reference_generator_statistics():
     """t1d_random_meals against the reference's RandomScenario.create_scenario as restated (and
     pinned by fixture G9) in the oracle: structure of the tables exactly, distributions per meal window within
