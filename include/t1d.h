@@ -149,6 +149,10 @@ typedef struct t1d_pid {
     void* min_bg; void* max_bg;   /* [n] */
     int32_t* n_low;           /* [n] += (bg < 70)  per step */
     int32_t* n_high;          /* [n] += (bg > 180) per step */
+    /* optional history on the device (NULL to skip): row trace_row + s receives step s of this call */
+    void* bg_trace;           /* [rows][n] mean BG of every step   (the BG column of show_history(), env.py:169-180) */
+    void* cgm_trace;          /* [rows][n] observation of every step (the CGM column) */
+    int64_t trace_row;
 } t1d_pid;
 
 /* BBController (controller/basal_bolus_ctrller.py:15-80) for closed-loop roll-outs: per-env constants the
@@ -162,7 +166,24 @@ typedef struct t1d_bb {
     void* prev_meal;          /* [n] state: info['meal'] of the previous step, g/min (0 after reset) */
     /* optional per-env accumulators over the roll-out (NULL to skip), as in t1d_pid */
     void* sum_risk; void* min_bg; void* max_bg; int32_t* n_low; int32_t* n_high;
+    /* optional history on the device, as in t1d_pid */
+    void* bg_trace; void* cgm_trace; int64_t trace_row;
 } t1d_bb;
+
+/* Per-env outcome statistics of a BG history kept on the device (analysis/report.py), one lane per env:
+ *   counts     int32 [5][n]: samples with BG > 180, BG < 70, 70 <= BG <= 180, BG > 250, BG < 50  (percent_stats,
+ *              report.py:74-92; divide by n_rows for the percentages)
+ *   pct        [2][n]: np.percentile(BG, q_lo) and (BG, q_hi) per env, exact (linear interpolation between order
+ *              statistics, found by radix selection), and zone uint8 [n]: CVGA zone 0..4 = A..E, 5 = none, from
+ *              the clipped percentiles (CVGA_analysis, report.py:198-217; q = 2.5 / 97.5 there)
+ *   risk_trace [n_chunks][2][n]: LBGI and HBGI of every chunk of `chunk` samples, from the chunk mean of
+ *              f(BG) = 1.509 (ln(BG)^1.084 - 5.381) over BG > 0 (risk_index_trace, report.py:95-110; chunk = 60)
+ * Any output pointer may be NULL.  n_chunks = ceil(n_rows / chunk). */
+typedef struct t1d_outcome {
+    int32_t* counts; void* pct; uint8_t* zone; void* risk_trace;
+    double q_lo, q_hi;
+    int32_t chunk;
+} t1d_outcome;
 
 int t1d_abi_version(void);
 const char* t1d_last_error(void);
@@ -222,6 +243,9 @@ int t1d_rollout_bb(t1d_ctx* ctx, const t1d_batch* batch, const t1d_bb* bb, int n
 int t1d_random_meals(int hip_device, uint64_t seed, int64_t env_offset, int64_t n, int dtype, int days,
                      const int32_t* start_minute_of_day, int start_scalar, int32_t* meal_time, void* meal_amt,
                      void* stream);
+
+int t1d_outcome_stats(int hip_device, int dtype, int64_t n, int64_t n_rows, const void* bg_trace,
+                      const t1d_outcome* out, void* stream);
 
 int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
 

@@ -17,7 +17,7 @@ Fixture ids follow SURVEY.md §8(c): G1 RHS known answers, G2 open-loop
 24 h traces (SciPy-default and tight), G3 pump, G4 sensor noise, G5 env-level
 reset/step, G6 config-1 closed loop (BBController), G7 upstream golden CSV
 re-generation check, G8 risk index, G9 random_init_bg + scenario draws,
-G10 PID closed loop.
+G10 PID closed loop, G11 analysis/report.py statistics.
 """
 import argparse
 import os
@@ -326,7 +326,33 @@ def g9_seeding():
     save("g9_seeding.npz", **out)
 
 
-ALL = {"G1": g1_rhs, "G3": g3_pump, "G4": g4_sensor, "G5": g5_env, "G6": g6_config1,
+# --------------------------------------------------------------------------- G11
+def g11_report():
+    """analysis/report.py statistics on a 24 h x 30 patient BG table (the G2 traces, spread per column so that every
+    range, risk sign and CVGA zone occurs)."""
+    from simglucose.analysis.report import percent_stats, CVGA_analysis
+    import matplotlib.pyplot as plt
+    g2 = np.load(os.path.join(OUT, "g2_openloop.npz"))
+    bg = g2["gsub_default"].T.copy()                                   # [1441, 30]
+    rs = np.random.RandomState(11)
+    scale = rs.uniform(0.1, 2.6, 30) * np.where(np.arange(30) % 3 == 2, -0.5, 1.0)     # every third column mirrored
+    shift = rs.uniform(-70, 30, 30)
+    bg = np.maximum(110.0 + (bg - 138.0) * scale[None, :] + shift[None, :], 5.0)
+    bg[::97, 3] = bg[5, 3]                                             # ties among the order statistics
+    df = pd.DataFrame(bg, columns=["p%02d" % k for k in range(30)])
+    p_stats, _, _ = percent_stats(df)
+    bmin, bmax, pa, pb, pc, pd_, pe = CVGA_analysis(df)
+    plt.close("all")
+    # risk_index_trace (report.py:95-133) cannot be recorded here: with the installed pandas 2.3 / numpy 2.2 its
+    # np.mean(DataFrame) yields a scalar and the function raises TypeError in pd.concat (an ordinary error of the
+    # reference under newer libraries).  Its formula is restated in the oracle and marked "parity unpinned".
+    cols = ["BG>180", "BG<70", "70<=BG<=180", "BG>250", "BG<50"]
+    save("g11_report.npz", bg=bg, percent=np.stack([p_stats[c].values for c in cols]),
+         bg_min=np.asarray(bmin, float), bg_max=np.asarray(bmax, float),
+         zones=np.array([pa, pb, pc, pd_, pe], float))
+
+
+ALL = {"G11": g11_report, "G1": g1_rhs, "G3": g3_pump, "G4": g4_sensor, "G5": g5_env, "G6": g6_config1,
        "G7": g7_upstream, "G8": g8_risk, "G9": g9_seeding, "G10": g10_pid}
 
 if __name__ == "__main__":

@@ -388,3 +388,44 @@ def closed_loop(patient_name, sensor, sensor_seed, scen_seed, n_steps, policy, s
                          ("CHO", "meal"), ("insulin", "insulin")):
             hist[key].append(o[src][0])
     return {k: np.array(v) for k, v in hist.items()}, np.array(actions)
+
+
+# ----------------------------------------------------------------------------- analysis/report.py (numbers only)
+def report_percent_stats(BG):
+    """percent_stats (analysis/report.py:74-92) on BG [rows, envs] -> [5, envs] percentages in the order
+    BG>180, BG<70, 70<=BG<=180, BG>250, BG<50.  Pinned by fixture G11."""
+    BG = np.asarray(BG, dtype=np.float64); n = float(len(BG))
+    return np.stack([(BG > 180).sum(0), (BG < 70).sum(0), ((BG >= 70) & (BG <= 180)).sum(0), (BG > 250).sum(0),
+                     (BG < 50).sum(0)]) / n * 100.0
+
+
+def report_cvga(BG):
+    """CVGA_analysis (analysis/report.py:198-217) -> BG_min, BG_max (clipped 2.5th / 97.5th percentiles per env),
+    zone fractions (A, B, C, D, E) and the per-env zone code 0..4 (5 = none).  Pinned by fixture G11."""
+    BG = np.asarray(BG, dtype=np.float64)
+    mn = np.clip(np.percentile(BG, 2.5, axis=0), 50, 400); mx = np.clip(np.percentile(BG, 97.5, axis=0), 50, 400)
+    A = (mn > 90) & (mn <= 110) & (mx >= 110) & (mx < 180)
+    B = (mn > 70) & (mn <= 110) & (mx >= 110) & (mx < 300)
+    Cz = ((mn > 90) & (mn <= 110) & (mx >= 300)) | ((mn <= 70) & (mx >= 110) & (mx < 180))
+    D = ((mn > 70) & (mn <= 90) & (mx >= 300)) | ((mn <= 70) & (mx >= 180) & (mx < 300))
+    E = (mn <= 70) & (mx >= 300)
+    m = float(len(mn))
+    frac = np.array([A.sum() / m, B.sum() / m - A.sum() / m, Cz.sum() / m, D.sum() / m, E.sum() / m])
+    zone = np.where(A, 0, np.where(B, 1, np.where(Cz, 2, np.where(D, 3, np.where(E, 4, 5)))))
+    return mn, mx, frac, zone
+
+
+def report_risk_index_trace(BG, chunk=60):
+    """risk_index_trace (analysis/report.py:95-110): per chunk of `chunk` rows and per env, f = mean over BG > 0 of
+    1.509 (ln(BG)^1.084 - 5.381); LBGI = 10 (f (f<0))^2, HBGI = 10 (f (f>0))^2 -> (LBGI, HBGI) each [n_chunks, envs].
+    PARITY UNPINNED: the reference function raises TypeError under the installed pandas 2.3 / numpy 2.2 (its
+    np.mean over a DataFrame no longer returns per-column means), so no fixture could be recorded; this restates
+    the formula with the per-column mean the code was written for."""
+    BG = np.asarray(BG, dtype=np.float64)
+    L, H = [], []
+    for i in range(0, len(BG), chunk):
+        c = BG[i:i + chunk]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            f = np.array([np.mean(1.509 * (np.log(col[col > 0]) ** 1.084 - 5.381)) for col in c.T])
+        L.append(10.0 * (f * (f < 0)) ** 2); H.append(10.0 * (f * (f > 0)) ** 2)
+    return np.array(L), np.array(H)

@@ -21,7 +21,7 @@ META_EATING = 0x100
 
 EXPORTS = ("t1d_abi_version", "t1d_last_error", "t1d_ctx_create", "t1d_ctx_set_option", "t1d_ctx_destroy", "t1d_reset",
            "t1d_step", "t1d_rollout_pid", "t1d_philox_normals", "t1d_sync", "t1d_split_tables",
-           "t1d_rollout_bb", "t1d_random_meals")
+           "t1d_rollout_bb", "t1d_random_meals", "t1d_outcome_stats")
 
 
 class T1DError(RuntimeError):
@@ -48,14 +48,22 @@ class Pid(C.Structure):
     """struct t1d_pid (include/t1d.h)"""
     _fields_ = [("P", C.c_double), ("I", C.c_double), ("D", C.c_double), ("target", C.c_double),
                 ("integ", C.c_void_p), ("prev", C.c_void_p), ("sum_risk", C.c_void_p),
-                ("min_bg", C.c_void_p), ("max_bg", C.c_void_p), ("n_low", C.c_void_p), ("n_high", C.c_void_p)]
+                ("min_bg", C.c_void_p), ("max_bg", C.c_void_p), ("n_low", C.c_void_p), ("n_high", C.c_void_p),
+                ("bg_trace", C.c_void_p), ("cgm_trace", C.c_void_p), ("trace_row", C.c_int64)]
 
 
 class Bb(C.Structure):
     """struct t1d_bb (include/t1d.h)"""
     _fields_ = [("target", C.c_double), ("basal", C.c_void_p), ("cr", C.c_void_p), ("cf", C.c_void_p),
                 ("prev_meal", C.c_void_p), ("sum_risk", C.c_void_p), ("min_bg", C.c_void_p), ("max_bg", C.c_void_p),
-                ("n_low", C.c_void_p), ("n_high", C.c_void_p)]
+                ("n_low", C.c_void_p), ("n_high", C.c_void_p),
+                ("bg_trace", C.c_void_p), ("cgm_trace", C.c_void_p), ("trace_row", C.c_int64)]
+
+
+class Outcome(C.Structure):
+    """struct t1d_outcome (include/t1d.h)"""
+    _fields_ = [("counts", C.c_void_p), ("pct", C.c_void_p), ("zone", C.c_void_p), ("risk_trace", C.c_void_p),
+                ("q_lo", C.c_double), ("q_hi", C.c_double), ("chunk", C.c_int32)]
 
 
 def build(force=False, verbose=False):
@@ -100,6 +108,7 @@ def lib():
     L.t1d_rollout_pid.argtypes = [vp, C.POINTER(Batch), C.POINTER(Pid), C.c_int, C.c_int, C.c_int, vp]
     L.t1d_rollout_bb.argtypes = [vp, C.POINTER(Batch), C.POINTER(Bb), C.c_int, C.c_int, C.c_int, vp]
     L.t1d_random_meals.argtypes = [C.c_int, u64, i64, i64, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.t1d_outcome_stats.argtypes = [C.c_int, C.c_int, i64, i64, vp, C.POINTER(Outcome), vp]
     L.t1d_philox_normals.argtypes = [vp, u64, i64, i64, u32, i32, i32, vp, vp]
     L.t1d_sync.argtypes = [vp, vp, C.POINTER(i32)]
     L.t1d_split_tables.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int]

@@ -223,7 +223,22 @@ class BatchedT1DSimEnv:
                 "risk": self.risk, "meal": self.meal, "insulin": self.insulin, "patient_state": self.x,
                 "t": self.t}
 
-    def rollout_pid(self, n_steps, P, I, D, target=140.0, pid_state=None, stats=None):
+    @staticmethod
+    def _set_trace(p, trace, n_steps):
+        """trace: None or dict(bg=tensor [rows, n], cgm=tensor [rows, n] (either optional), row=first row to write)"""
+        p.bg_trace = p.cgm_trace = None
+        p.trace_row = 0
+        if trace:
+            row = int(trace.get("row", 0))
+            for k, f in (("bg", "bg_trace"), ("cgm", "cgm_trace")):
+                if trace.get(k) is not None:
+                    if trace[k].shape[0] < row + n_steps or not trace[k].is_contiguous():
+                        raise ValueError("trace['%s'] needs at least row + n_steps contiguous rows" % k)
+                    setattr(p, f, trace[k].data_ptr())
+            p.trace_row = row
+            trace["row"] = row + int(n_steps)
+
+    def rollout_pid(self, n_steps, P, I, D, target=140.0, pid_state=None, stats=None, trace=None):
         """n_steps closed-loop PID steps in one launch (PIDController.policy + env.step per step).
         pid_state: dict(integ, prev) tensors [n] (created zeroed if None).  stats: optional dict
         with any of sum_risk, min_bg, max_bg (float [n]) and n_low, n_high (int32 [n])."""
@@ -236,6 +251,7 @@ class BatchedT1DSimEnv:
         stats = stats or {}
         for k in ("sum_risk", "min_bg", "max_bg", "n_low", "n_high"):
             setattr(p, k, stats[k].data_ptr() if k in stats else None)
+        self._set_trace(p, trace, n_steps)
         self._b.cho = None
         self._b.flags = self._flags0
         if self._clock is not None:
@@ -260,7 +276,7 @@ class BatchedT1DSimEnv:
         mk = lambda v: torch.as_tensor(v[self.patient_idx], dtype=self.dtype, device=self.device).contiguous()
         return {"basal": mk(basal), "cr": mk(cr), "cf": mk(cf)}
 
-    def rollout_bb(self, n_steps, target=140.0, bb_state=None, stats=None):
+    def rollout_bb(self, n_steps, target=140.0, bb_state=None, stats=None, trace=None):
         """n_steps closed-loop BBController steps in one launch (SimObj.simulate with BBController: policy from
         the previous observation and the previous step's announced meal, then env.step).  bb_state: dict with
         basal, cr, cf (see bb_constants) and prev_meal [n] (created if None; prev_meal = 0 right after reset).
@@ -275,6 +291,7 @@ class BatchedT1DSimEnv:
         stats = stats or {}
         for k in ("sum_risk", "min_bg", "max_bg", "n_low", "n_high"):
             setattr(p, k, stats[k].data_ptr() if k in stats else None)
+        self._set_trace(p, trace, n_steps)
         self._b.cho = None
         self._b.flags = self._flags0
         if self._clock is not None:

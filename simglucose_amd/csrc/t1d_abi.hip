@@ -55,6 +55,7 @@ template <typename T> struct PidArgs {
     int n_steps;
     int kind;               // 0 = PIDController, 1 = BBController
     const T* bb_basal; const T* bb_cr; const T* bb_cf; T* bb_prev_meal;
+    T* bg_trace; T* cgm_trace; int64_t trace_row;
 };
 
 // Row k of a [K][n] array as a wave-uniform base pointer: the lane index i then rides in ONE 32-bit
@@ -814,6 +815,8 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
         o = step_body<MATH, T, P, NoHook, false, true, PR>(a, p, i, e, u, bolus, true, NoHook(), pr);
         obs = o.cgm;
         prev_meal = o.meal;
+        if (c.bg_trace) c.bg_trace[(c.trace_row + s) * a.n + i] = o.bg;
+        if (c.cgm_trace) c.cgm_trace[(c.trace_row + s) * a.n + i] = o.cgm;
         pre_prev_cgm = e.prev_cgm;
         e.prev_cgm = o.cgm;                      // CGM history advances every step
         if (c.sum_risk) { T l, h, r; risk_index1<MATH>(o.bg, l, h, r); sum_risk += r; }
@@ -993,6 +996,103 @@ __global__ __launch_bounds__(kBlock) void random_meals_kernel(uint64_t seed, int
         }
     }
     for (; w < rows; ++w) { meal_time[(int64_t)w * n + i] = INT_MAX; meal_amt[(int64_t)w * n + i] = T(0); }
+}
+
+// ---- outcome statistics of a BG history on the device (analysis/report.py) ------------------------------
+// One lane = one env, rows are read coalesced.  The two percentiles are exact: the order statistics are found
+// by radix selection on the order-preserving integer image of the values (one pass over the env's column per
+// bit), then interpolated as numpy's default 'linear' method does.
+template <typename T> struct OKey;
+template <> struct OKey<double> {
+    typedef uint64_t U; static constexpr int bits = 64;
+    static __device__ __forceinline__ U key(double v) { const U u = (U)__double_as_longlong(v); return (u >> 63) ? ~u : (u | 0x8000000000000000ull); }
+    static __device__ __forceinline__ double val(U k) { const U u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k; return __longlong_as_double((long long)u); }
+};
+template <> struct OKey<float> {
+    typedef uint32_t U; static constexpr int bits = 32;
+    static __device__ __forceinline__ U key(float v) { const U u = __float_as_uint(v); return (u >> 31) ? ~u : (u | 0x80000000u); }
+    static __device__ __forceinline__ float val(U k) { const U u = (k >> 31) ? (k & 0x7fffffffu) : ~k; return __uint_as_float(u); }
+};
+
+// k-th smallest (0-based) of column i, and the next order statistic after it
+template <typename T>
+__device__ void order_stat_pair(const T* __restrict__ tr, int64_t n, int64_t rows, int64_t i, int64_t k, T& vk, T& vk1)
+{
+    typedef typename OKey<T>::U U;
+    U prefix = 0;
+    for (int bit = OKey<T>::bits - 1; bit >= 0; --bit) {
+        const U test = prefix | ((U)1 << bit);
+        int64_t c = 0;
+        for (int64_t r = 0; r < rows; ++r) c += OKey<T>::key(tr[r * n + i]) < test;
+        if (c <= k) prefix = test;
+    }
+    int64_t le = 0; U next = ~(U)0; bool have = false;
+    for (int64_t r = 0; r < rows; ++r) {
+        const U key = OKey<T>::key(tr[r * n + i]);
+        le += key <= prefix;
+        if (key > prefix && (!have || key < next)) { next = key; have = true; }
+    }
+    vk = OKey<T>::val(prefix);
+    vk1 = (le > k + 1 || !have) ? vk : OKey<T>::val(next);      // duplicates of the k-th value cover rank k + 1
+}
+
+template <typename T>
+__device__ __forceinline__ T percentile_linear(const T* tr, int64_t n, int64_t rows, int64_t i, double q)
+{
+    const double pos = (double)(rows - 1) * q / 100.0;
+    int64_t lo = (int64_t)floor(pos);
+    lo = lo < 0 ? 0 : (lo > rows - 1 ? rows - 1 : lo);
+    const double t = pos - (double)lo;
+    T a, b;
+    order_stat_pair(tr, n, rows, i, lo, a, b);
+    if (lo >= rows - 1) b = a;
+    const double d = (double)b - (double)a;                       // numpy _lerp
+    double r = (double)a + d * t;
+    if (t >= 0.5) r = (double)b - d * (1.0 - t);
+    if (b == a) r = (double)a;
+    return (T)r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void outcome_kernel(int64_t n, int64_t rows, const T* __restrict__ tr, int32_t* counts,
+                                                         T* pct, uint8_t* zone, T* risk_trace, double q_lo, double q_hi, int chunk)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (counts || risk_trace) {
+        int c180 = 0, c70 = 0, cin = 0, c250 = 0, c50 = 0;
+        double fsum = 0.0; int fcnt = 0; int64_t ch = 0;
+        for (int64_t r = 0; r < rows; ++r) {
+            const T bg = tr[r * n + i];
+            c180 += bg > T(180); c70 += bg < T(70); cin += (bg >= T(70)) & (bg <= T(180)); c250 += bg > T(250); c50 += bg < T(50);
+            if (risk_trace) {
+                if (bg > T(0)) { fsum += 1.509 * (pow(log((double)bg), 1.084) - 5.381); ++fcnt; }      // report.py:98-100
+                if ((r + 1) % chunk == 0 || r == rows - 1) {
+                    const double f = fcnt ? fsum / (double)fcnt : __builtin_nan("");
+                    const double fl = f < 0.0 ? f : 0.0, fh = f > 0.0 ? f : 0.0;                        // report.py:104-105
+                    risk_trace[(ch * 2) * n + i] = (T)(f == f ? 10.0 * fl * fl : f);
+                    risk_trace[(ch * 2 + 1) * n + i] = (T)(f == f ? 10.0 * fh * fh : f);
+                    fsum = 0.0; fcnt = 0; ++ch;
+                }
+            }
+        }
+        if (counts) { counts[i] = c180; counts[n + i] = c70; counts[2 * n + i] = cin; counts[3 * n + i] = c250; counts[4 * n + i] = c50; }
+    }
+    if (pct || zone) {
+        const T plo = percentile_linear(tr, n, rows, i, q_lo), phi = percentile_linear(tr, n, rows, i, q_hi);
+        if (pct) { pct[i] = plo; pct[n + i] = phi; }
+        if (zone) {                                                     // CVGA_analysis (report.py:198-217)
+            double mn = (double)plo, mx = (double)phi;
+            mn = mn < 50.0 ? 50.0 : (mn > 400.0 ? 400.0 : mn);
+            mx = mx < 50.0 ? 50.0 : (mx > 400.0 ? 400.0 : mx);
+            const bool A = mn > 90 && mn <= 110 && mx >= 110 && mx < 180;
+            const bool B = mn > 70 && mn <= 110 && mx >= 110 && mx < 300;
+            const bool Cz = (mn > 90 && mn <= 110 && mx >= 300) || (mn <= 70 && mx >= 110 && mx < 180);
+            const bool D = (mn > 70 && mn <= 90 && mx >= 300) || (mn <= 70 && mx >= 180 && mx < 300);
+            const bool E = mn <= 70 && mx >= 300;
+            zone[i] = A ? 0 : (B ? 1 : (Cz ? 2 : (D ? 3 : (E ? 4 : 5))));
+        }
+    }
 }
 
 } // namespace t1d
@@ -1537,6 +1637,7 @@ static PidArgs<T> make_pid(const t1d_pid* p, int n_steps)
     c.min_bg = (T*)p->min_bg; c.max_bg = (T*)p->max_bg; c.n_low = p->n_low; c.n_high = p->n_high;
     c.n_steps = n_steps;
     c.kind = 0; c.bb_basal = nullptr; c.bb_cr = nullptr; c.bb_cf = nullptr; c.bb_prev_meal = nullptr;
+    c.bg_trace = (T*)p->bg_trace; c.cgm_trace = (T*)p->cgm_trace; c.trace_row = p->trace_row;
     return c;
 }
 
@@ -1549,6 +1650,7 @@ static PidArgs<T> make_bb(const t1d_bb* p, int n_steps)
     c.min_bg = (T*)p->min_bg; c.max_bg = (T*)p->max_bg; c.n_low = p->n_low; c.n_high = p->n_high;
     c.n_steps = n_steps;
     c.kind = 1; c.bb_basal = (const T*)p->basal; c.bb_cr = (const T*)p->cr; c.bb_cf = (const T*)p->cf; c.bb_prev_meal = (T*)p->prev_meal;
+    c.bg_trace = (T*)p->bg_trace; c.cgm_trace = (T*)p->cgm_trace; c.trace_row = p->trace_row;
     return c;
 }
 
@@ -1634,6 +1736,28 @@ extern "C" int t1d_random_meals(int hip_device, uint64_t seed, int64_t env_offse
     else
         hipLaunchKernelGGL(random_meals_kernel<float>, grid_for(n), dim3(kBlock), 0, s, seed, env_offset, n, days,
                            start_minute_of_day, start_scalar, meal_time, (float*)meal_amt, ms);
+    T1D_HIP(hipGetLastError());
+    return T1D_OK;
+}
+
+extern "C" int t1d_outcome_stats(int hip_device, int dtype, int64_t n, int64_t n_rows, const void* bg_trace,
+                                 const t1d_outcome* out, void* stream)
+{
+    if (!bg_trace || !out) return fail(T1D_E_INVALID, "t1d_outcome_stats: NULL argument");
+    if (n < 1 || n > (int64_t)1 << 28 || n_rows < 1) return fail(T1D_E_INVALID, "t1d_outcome_stats: n / n_rows out of range");
+    if (dtype != T1D_F64 && dtype != T1D_F32) return fail(T1D_E_INVALID, "t1d_outcome_stats: bad dtype");
+    if (out->risk_trace && out->chunk < 1) return fail(T1D_E_INVALID, "t1d_outcome_stats: chunk < 1");
+    if ((out->pct || out->zone) && !(out->q_lo >= 0.0 && out->q_lo <= 100.0 && out->q_hi >= 0.0 && out->q_hi <= 100.0))
+        return fail(T1D_E_INVALID, "t1d_outcome_stats: percentiles must be in [0, 100]");
+    T1D_HIP(hipSetDevice(hip_device));
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = out->chunk > 0 ? out->chunk : 60;
+    if (dtype == T1D_F64)
+        hipLaunchKernelGGL(outcome_kernel<double>, grid_for(n), dim3(kBlock), 0, s, n, n_rows, (const double*)bg_trace, out->counts,
+                           (double*)out->pct, out->zone, (double*)out->risk_trace, out->q_lo, out->q_hi, chunk);
+    else
+        hipLaunchKernelGGL(outcome_kernel<float>, grid_for(n), dim3(kBlock), 0, s, n, n_rows, (const float*)bg_trace, out->counts,
+                           (float*)out->pct, out->zone, (float*)out->risk_trace, out->q_lo, out->q_hi, chunk);
     T1D_HIP(hipGetLastError());
     return T1D_OK;
 }

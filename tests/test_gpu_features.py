@@ -274,6 +274,59 @@ def test_split_integrator_other_substep_counts_and_table_rebuild(n_sub):
     e.sync(raise_on_status=False)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_outcome_statistics_match_reference_report(golden, dtype):
+    """t1d_outcome_stats on fixture G11: the reference's percent_stats and CVGA_analysis outputs
+    exactly (percentiles by radix selection == np.percentile), zones, and the chunked risk trace against the
+    oracle's restatement of risk_index_trace."""
+    import torch
+    from simglucose_amd.analysis import report
+    from oracle import t1d_oracle as O
+    g = golden("g11_report.npz")
+    dt = torch.float64 if dtype == "f64" else torch.float32
+    bg = torch.as_tensor(g["bg"], dtype=dt, device="cuda:0").contiguous()
+    ref_bg = bg.double().cpu().numpy()                       # what the kernel sees (fp32 run: rounded inputs)
+    r = report.outcome_stats(bg)
+    want = O.report_percent_stats(ref_bg)
+    assert np.array_equal(r["counts"].cpu().numpy(), np.rint(want * len(ref_bg) / 100.0).astype(np.int64))
+    assert np.abs(r["percent"].cpu().numpy() - want).max() < 1e-12
+    mn, mx, frac, zone = O.report_cvga(ref_bg)
+    tol = 1e-12 if dtype == "f64" else 2e-5
+    assert np.abs(r["bg_min"].double().cpu().numpy() - mn).max() < tol and np.abs(r["bg_max"].double().cpu().numpy() - mx).max() < tol
+    if dtype == "f64":
+        assert np.abs(r["percent"].cpu().numpy() - g["percent"]).max() < 1e-12
+        assert np.abs(r["bg_min"].cpu().numpy() - g["bg_min"]).max() < 1e-12 and np.abs(r["bg_max"].cpu().numpy() - g["bg_max"]).max() < 1e-12
+        assert np.array_equal(r["zone"].cpu().numpy(), zone)
+        out = report.CVGA_analysis(bg)
+        assert np.abs(np.array(out[2:]) - g["zones"]).max() < 1e-15
+    L, H = O.report_risk_index_trace(ref_bg)
+    rtol = 1e-10 if dtype == "f64" else 1e-4
+    assert np.allclose(r["lbgi"].double().cpu().numpy(), L, rtol=rtol, atol=rtol) and np.allclose(r["hbgi"].double().cpu().numpy(), H, rtol=rtol, atol=rtol)
+    # a history written by the roll-out kernel: rows = reset + every step, equal to stepping on the host
+    from simglucose_amd import scenario_batch as sb
+    n, K = 256, 96
+    envs = []
+    for _ in range(2):
+        e = _mk(patient=np.arange(n) % 30, sensor="Dexcom", dtype=dt, noise="philox", seed=7, n_sub=4)
+        mt, ma = sb.random_meal_tables(n, days=1, seed=5, device=e.device, dtype=dt)
+        e.set_meals(mt, ma); e.reset()
+        envs.append(e)
+    tr = {"bg": torch.zeros(K + 1, n, dtype=dt, device="cuda:0"), "cgm": torch.zeros(K + 1, n, dtype=dt, device="cuda:0"), "row": 1}
+    tr["bg"][0] = envs[0].bg; tr["cgm"][0] = envs[0].cgm
+    st = envs[0].rollout_bb(40, trace=tr)
+    envs[0].rollout_bb(K - 40, bb_state=st, trace=tr)
+    assert tr["row"] == K + 1
+    st2 = None
+    host = [envs[1].bg.clone()]
+    for k in range(K):
+        st2 = envs[1].rollout_bb(1, bb_state=st2)
+        host.append(envs[1].bg.clone())
+    assert torch.allclose(torch.stack(host).double(), tr["bg"].double(), rtol=0, atol=1e-9 if dtype == "f64" else 1e-3)
+    s = report.outcome_stats(tr["bg"])
+    assert int(s["counts"][:3].sum(0).min()) == K + 1 == int(s["counts"][:3].sum(0).max())      # the three ranges partition the samples
+    assert envs[0].sync() == 0 and envs[1].sync() == 0
+
+
 def test_random_meal_tables_match_reference_generator_statistics():
     """t1d_random_meals against the reference's RandomScenario.create_scenario as restated (and
     pinned by fixture G9) in the oracle: structure of the tables exactly, distributions per meal window within

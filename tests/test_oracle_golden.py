@@ -204,3 +204,15 @@ def test_random_scenario_restatement(golden):
             n = int(g["scen_count"][i, d])
             assert len(t) == n
             assert np.array_equal(t, g["scen_time"][i, d, :n]) and np.array_equal(a, g["scen_amount"][i, d, :n])
+
+
+def test_report_statistics_restatement(golden):
+    """G11: percent_stats and CVGA_analysis of the reference (analysis/report.py) on a 1441 x 30 BG table."""
+    g = golden("g11_report.npz")
+    assert np.abs(O.report_percent_stats(g["bg"]) - g["percent"]).max() < 1e-12
+    mn, mx, frac, zone = O.report_cvga(g["bg"])
+    assert np.abs(mn - g["bg_min"]).max() < 1e-12 and np.abs(mx - g["bg_max"]).max() < 1e-12
+    assert np.abs(frac - g["zones"]).max() < 1e-15
+    assert sorted(set(zone.tolist())) == [0, 1, 2, 3, 4, 5]          # the fixture exercises every zone
+    L, H = O.report_risk_index_trace(g["bg"])                        # parity unpinned (see its docstring): sanity only
+    assert L.shape == (25, 30) and np.all((L == 0) | (H == 0))
