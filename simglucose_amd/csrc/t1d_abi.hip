@@ -472,6 +472,8 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
     T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
     __shared__ int queue;
+    __shared__ T lconst[8];                              // pump and sensor limits: read from LDS where used, so that they
+                                                         // do not sit in (spilled) scalar registers across the whole kernel
     for (int j = threadIdx.x; j < DP_COUNT * STRIDE; j += kS1Threads) {
         const int r = j / STRIDE, c = j % STRIDE;
         ldp[j] = c < a.np ? a.dpar[r * kMaxPatients + c] : T(0);
@@ -480,7 +482,12 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         const int r = j / STRIDE, c = j % STRIDE;
         lpr[j] = c < a.np ? a.prop[r * a.np_pad + c] : T(0);
     }
-    if (threadIdx.x == 0) queue = 0;
+    if (threadIdx.x == 0) {
+        queue = 0;
+        lconst[0] = a.pump.inc_basal; lconst[1] = a.pump.min_basal; lconst[2] = a.pump.max_basal;
+        lconst[3] = a.pump.inc_bolus; lconst[4] = a.pump.min_bolus; lconst[5] = a.pump.max_bolus;
+        lconst[6] = a.sen.vmin; lconst[7] = a.sen.vmax;
+    }
     __syncthreads();
     // This workgroup owns a contiguous run of 64-env chunks; its waves draw them from a queue in LDS.  The
     // SIMD issues oldest-wave-first, so with a fixed share per wave the first wave of a SIMD would race ahead
@@ -531,9 +538,12 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         if (a.flags & T1D_BATCH_NO_PUMP) {
             q_basal = basal; q_bolus = a.bolus ? bolus : T(0);
         } else {
-            q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
-            q_bolus = a.pump.min_bolus > T(0) ? a.pump.min_bolus : T(0);
-            if (a.bolus) q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
+            int z = 0;
+            asm volatile("" : "+v"(z));                  // opaque index: the reads below stay inside the chunk loop
+            const T* lc = lconst + z;
+            q_basal = pump_quantise(basal, lc[0], lc[1], lc[2]);                                   // env.py:51
+            q_bolus = lc[4] > T(0) ? lc[4] : T(0);
+            if (a.bolus) q_bolus = pump_quantise(bolus, lc[3], lc[4], lc[5]);                      // env.py:52
         }
         const T insulin = q_basal + q_bolus;
         const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
@@ -574,8 +584,11 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         const T gsub = e.x[12] * pl(DP_IVG);                                                       // t1dpatient.py:217-218
         if (due) {                                                                                 // cgm.py:26-36
             T c = gsub + noise;
-            c = c > a.sen.vmin ? c : a.sen.vmin;
-            c = c < a.sen.vmax ? c : a.sen.vmax;
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const T vmin = lconst[6 + z], vmax = lconst[7 + z];
+            c = c > vmin ? c : vmin;
+            c = c < vmax ? c : vmax;
             last_cgm = c;
             at(row(a.x, a.n, 16), i) = c;
         }

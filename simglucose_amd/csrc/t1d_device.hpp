@@ -126,33 +126,44 @@ __device__ __forceinline__ float t_max(float a, float b) { return fmaxf(a, b); }
 // r = v - n ln2 (two-part), Taylor polynomial of degree DEG on |r| <= 0.347, scale by 2^n.
 // DEG 12: truncation 1.7e-16 relative (19 VALU ops; ocml tanh: ~150);  DEG 10: 2.2e-13 (17 ops) -- used for
 // the gastric-emptying term, where it moves glucose by < 1e-10 mg/dL.
-template <int DEG = 12>
+// A 64-bit literal cannot be an operand of a VOP3 fp64 instruction, so every polynomial coefficient lives in a
+// register pair.  LOCAL = true materialises it in scalar registers right where it is used (two s_mov_b32): for
+// code that runs once per env-step (risk index, noise) this stops the compiler from hoisting ~20 coefficients out
+// of the tile loop into VGPRs that then stay allocated -- or get spilled -- across the integration loops.
+template <bool LOCAL>
+__device__ __forceinline__ double kc(double c)
+{
+    if (LOCAL) asm volatile("" : "+s"(c));
+    return c;
+}
+
+template <int DEG = 12, bool LOCAL = false>
 __device__ __forceinline__ double exp_core(double v)
 {
     const double n = rint(v * 1.4426950408889634074);
-    double r = fma(-n, 6.93147180369123816490e-01, v);
-    r = fma(-n, 1.90821492927058770002e-10, r);
+    double r = fma(-n, kc<LOCAL>(6.93147180369123816490e-01), v);
+    r = fma(-n, kc<LOCAL>(1.90821492927058770002e-10), r);
     double p;
     if (DEG >= 12) {
         p = 2.08767569878680989792e-09;                // 1/12!
-        p = fma(p, r, 2.50521083854417187751e-08);     // 1/11!
-        p = fma(p, r, 2.75573192239858906526e-07);     // 1/10!
+        p = fma(p, r, kc<LOCAL>(2.50521083854417187751e-08));     // 1/11!
+        p = fma(p, r, kc<LOCAL>(2.75573192239858906526e-07));     // 1/10!
     } else {
         p = 2.75573192239858906526e-07;                // 1/10!
     }
-    p = fma(p, r, 2.75573192239858906526e-06);        // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);        // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);        // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);        // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);        // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);        // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);        // 1/3!
+    p = fma(p, r, kc<LOCAL>(2.75573192239858906526e-06));        // 1/9!
+    p = fma(p, r, kc<LOCAL>(2.48015873015873015873e-05));        // 1/8!
+    p = fma(p, r, kc<LOCAL>(1.98412698412698412698e-04));        // 1/7!
+    p = fma(p, r, kc<LOCAL>(1.38888888888888888889e-03));        // 1/6!
+    p = fma(p, r, kc<LOCAL>(8.33333333333333333333e-03));        // 1/5!
+    p = fma(p, r, kc<LOCAL>(4.16666666666666666667e-02));        // 1/4!
+    p = fma(p, r, kc<LOCAL>(1.66666666666666666667e-01));        // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, (int)n);
 }
-template <int DEG = 12>
+template <int DEG = 12, bool LOCAL = false>
 __device__ __forceinline__ float exp_core(float v) { return __expf(v); }
 
 // a / b for finite, normal b: v_rcp_f64 seed (measured: 4.6e-8 relative), one Newton step (2.2e-15), then
@@ -168,6 +179,7 @@ __device__ __forceinline__ float fdiv(float a, float b) { return __fdividef(a, b
 
 // log(v) for finite v > 0 (fdlibm-style: v = 2^e m, m in [sqrt(1/2), sqrt 2), s = f/(2+f),
 // degree-7 even polynomial in s^2); ~35 VALU ops, < 1 ulp.
+template <bool LOCAL = false>
 __device__ __forceinline__ double log_core(double v)
 {
     int e = __builtin_amdgcn_frexp_exp(v);            // v = m 2^e, m in [0.5, 1)
@@ -178,13 +190,14 @@ __device__ __forceinline__ double log_core(double v)
     const double f = m - 1.0;
     const double s = fdiv(f, 2.0 + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, kc<LOCAL>(2.222219843214978396e-01)), kc<LOCAL>(3.999999999940941908e-01));
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, kc<LOCAL>(1.818357216161805012e-01)), kc<LOCAL>(2.857142874366239149e-01)), kc<LOCAL>(6.666666666666735130e-01));
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
-    return fma(dk, 6.93147180369123816490e-01, f - (hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+    return fma(dk, kc<LOCAL>(6.93147180369123816490e-01), f - (hfsq - fma(s, hfsq + R, dk * kc<LOCAL>(1.90821492927058770002e-10))));
 }
+template <bool LOCAL = false>
 __device__ __forceinline__ float log_core(float v) { return __logf(v); }
 
 // ---- T1DPatient.model (t1dpatient.py:119-208): k = dx/dt ------------------------------------------
@@ -573,7 +586,7 @@ __device__ __forceinline__ MinuteIn<T> eat_minute(P& p, const T (&x)[13], T meal
         u.aa = u.has_dbar ? p(DP_CAA) / dsafe : T(0);       // :136
         u.cc = u.has_dbar ? p(DP_CCC) / dsafe : T(0);       // :137
     } else {
-        const T inv2 = u.has_dbar ? T(2) / dsafe : T(0);
+        const T inv2 = u.has_dbar ? fdiv(T(2), dsafe) : T(0);
         u.aa = p(DP_CAA) * inv2;
         u.cc = p(DP_CCC) * inv2;
     }
@@ -588,7 +601,7 @@ template <typename T>
 __device__ __forceinline__ T pump_quantise(T amount, T inc, T lo, T hi)
 {
     T v = amount * T(6000);
-    v = t_rint(v / inc) * inc;
+    v = t_rint(v / inc) * inc;          // IEEE division: decides which increment an exact tie rounds to
     v = v / T(6000);
     v = v < hi ? v : hi;
     v = v > lo ? v : lo;
@@ -610,8 +623,8 @@ __device__ __forceinline__ void risk_index1(T bg, T& lbgi, T& hbgi, T& ri)
         const T inf = T(__builtin_huge_val());
         const T nan = T(__builtin_nan(""));
         const bool regular = bg > T(1) && bg < inf;            // log(bg) in (0, inf)
-        const T u = log_core(regular ? bg : T(2));
-        const T pw = exp_core(T(1.084) * log_core(u));
+        const T u = log_core<true>(regular ? bg : T(2));
+        const T pw = exp_core<12, true>(T(1.084) * log_core<true>(u));
         const T freg = T(1.509) * (pw - T(5.381));
         // numpy: log(1)**p = 0; log(0) = -inf and (-inf)**p = +inf; log(inf)**p = inf; log of a
         // negative or of a value in (0,1) raised to a non-integer power, and NaN, give NaN
