@@ -152,6 +152,8 @@ typedef struct t1d_pid {
     /* optional history on the device (NULL to skip): row trace_row + s receives step s of this call */
     void* bg_trace;           /* [rows][n] mean BG of every step   (the BG column of show_history(), env.py:169-180) */
     void* cgm_trace;          /* [rows][n] observation of every step (the CGM column) */
+    void* cho_trace;          /* [rows][n] mean announced CHO, g/min  (the CHO column) */
+    void* insulin_trace;      /* [rows][n] mean pump output, U/min    (the insulin column) */
     int64_t trace_row;
 } t1d_pid;
 
@@ -167,7 +169,7 @@ typedef struct t1d_bb {
     /* optional per-env accumulators over the roll-out (NULL to skip), as in t1d_pid */
     void* sum_risk; void* min_bg; void* max_bg; int32_t* n_low; int32_t* n_high;
     /* optional history on the device, as in t1d_pid */
-    void* bg_trace; void* cgm_trace; int64_t trace_row;
+    void* bg_trace; void* cgm_trace; void* cho_trace; void* insulin_trace; int64_t trace_row;
 } t1d_bb;
 
 /* Per-env outcome statistics of a BG history kept on the device (analysis/report.py), one lane per env:

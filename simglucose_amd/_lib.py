@@ -49,7 +49,8 @@ class Pid(C.Structure):
     _fields_ = [("P", C.c_double), ("I", C.c_double), ("D", C.c_double), ("target", C.c_double),
                 ("integ", C.c_void_p), ("prev", C.c_void_p), ("sum_risk", C.c_void_p),
                 ("min_bg", C.c_void_p), ("max_bg", C.c_void_p), ("n_low", C.c_void_p), ("n_high", C.c_void_p),
-                ("bg_trace", C.c_void_p), ("cgm_trace", C.c_void_p), ("trace_row", C.c_int64)]
+                ("bg_trace", C.c_void_p), ("cgm_trace", C.c_void_p), ("cho_trace", C.c_void_p),
+                ("insulin_trace", C.c_void_p), ("trace_row", C.c_int64)]
 
 
 class Bb(C.Structure):
@@ -57,7 +58,8 @@ class Bb(C.Structure):
     _fields_ = [("target", C.c_double), ("basal", C.c_void_p), ("cr", C.c_void_p), ("cf", C.c_void_p),
                 ("prev_meal", C.c_void_p), ("sum_risk", C.c_void_p), ("min_bg", C.c_void_p), ("max_bg", C.c_void_p),
                 ("n_low", C.c_void_p), ("n_high", C.c_void_p),
-                ("bg_trace", C.c_void_p), ("cgm_trace", C.c_void_p), ("trace_row", C.c_int64)]
+                ("bg_trace", C.c_void_p), ("cgm_trace", C.c_void_p), ("cho_trace", C.c_void_p),
+                ("insulin_trace", C.c_void_p), ("trace_row", C.c_int64)]
 
 
 class Outcome(C.Structure):

@@ -72,3 +72,35 @@ def CVGA_analysis(bg):
     m = float(z.numel())
     frac = [float((z == k).sum()) / m for k in range(5)]
     return (r["bg_min"], r["bg_max"]) + tuple(frac)
+
+
+def history_frame(trace, env_index, start_time, sample_time):
+    """T1DSimEnv.show_history() (simulation/env.py:169-180) for one env of a device-resident history (see
+    BatchedT1DSimEnv.new_trace): DataFrame indexed by Time with columns BG, CGM, CHO, insulin, LBGI, HBGI, Risk;
+    the last row has no CHO / insulin, as upstream."""
+    from datetime import timedelta
+    import numpy as np
+    import pandas as pd
+    from .risk import risk_index
+    rows = int(trace["row"])
+    col = lambda k: trace[k][:rows, env_index].double().cpu().numpy()
+    bg, cgm = col("bg"), col("cgm")
+    cho = np.append(col("cho")[1:], np.nan)                 # CHO_hist / insulin_hist are one entry shorter (env.py:88-89,174-175)
+    ins = np.append(col("insulin")[1:], np.nan)
+    risk = np.array([risk_index([v], 1) for v in bg], dtype=float)
+    df = pd.DataFrame({"Time": [start_time + timedelta(minutes=float(sample_time) * k) for k in range(rows)],
+                       "BG": bg, "CGM": cgm, "CHO": cho, "insulin": ins,
+                       "LBGI": risk[:, 0], "HBGI": risk[:, 1], "Risk": risk[:, 2]})
+    return df.set_index("Time")
+
+
+def save_histories(trace, env_indices, names, path, start_time, sample_time):
+    """SimObj.save_results (simulation/sim_engine.py:44-49) for a selected subset of envs: <path>/<name>.csv."""
+    import os
+    os.makedirs(path, exist_ok=True)
+    out = []
+    for i, name in zip(env_indices, names):
+        f = os.path.join(path, str(name) + ".csv")
+        history_frame(trace, i, start_time, sample_time).to_csv(f)
+        out.append(f)
+    return out

@@ -225,18 +225,33 @@ class BatchedT1DSimEnv:
 
     @staticmethod
     def _set_trace(p, trace, n_steps):
-        """trace: None or dict(bg=tensor [rows, n], cgm=tensor [rows, n] (either optional), row=first row to write)"""
-        p.bg_trace = p.cgm_trace = None
+        """trace: None or dict with any of bg, cgm, cho, insulin (tensors [rows, n]) and row = first row to write
+        (see new_trace)"""
+        p.bg_trace = p.cgm_trace = p.cho_trace = p.insulin_trace = None
         p.trace_row = 0
         if trace:
             row = int(trace.get("row", 0))
-            for k, f in (("bg", "bg_trace"), ("cgm", "cgm_trace")):
+            for k, f in (("bg", "bg_trace"), ("cgm", "cgm_trace"), ("cho", "cho_trace"), ("insulin", "insulin_trace")):
                 if trace.get(k) is not None:
                     if trace[k].shape[0] < row + n_steps or not trace[k].is_contiguous():
                         raise ValueError("trace['%s'] needs at least row + n_steps contiguous rows" % k)
                     setattr(p, f, trace[k].data_ptr())
             p.trace_row = row
             trace["row"] = row + int(n_steps)
+
+    def new_trace(self, n_steps, columns=("bg", "cgm", "cho", "insulin")):
+        """Device-resident history for the next `n_steps` roll-out steps, laid out as T1DSimEnv's history lists
+        (simulation/env.py:119-155,169-180): row 0 holds what reset() recorded (BG0 and CGM sample #0; CHO and
+        insulin have no row for the last time stamp, so their row r is the action of step r), row r >= 1 step r.
+        Call right after reset(); pass the dict as rollout_*(trace=...)."""
+        tr = {"row": 1}
+        for k in columns:
+            tr[k] = torch.full((int(n_steps) + 1, self.n), float("nan"), dtype=self.dtype, device=self.device)
+        if "bg" in tr:
+            tr["bg"][0] = self.bg
+        if "cgm" in tr:
+            tr["cgm"][0] = self.prev_cgm
+        return tr
 
     def rollout_pid(self, n_steps, P, I, D, target=140.0, pid_state=None, stats=None, trace=None):
         """n_steps closed-loop PID steps in one launch (PIDController.policy + env.step per step).

@@ -55,7 +55,7 @@ template <typename T> struct PidArgs {
     int n_steps;
     int kind;               // 0 = PIDController, 1 = BBController
     const T* bb_basal; const T* bb_cr; const T* bb_cf; T* bb_prev_meal;
-    T* bg_trace; T* cgm_trace; int64_t trace_row;
+    T* bg_trace; T* cgm_trace; T* cho_trace; T* ins_trace; int64_t trace_row;
 };
 
 // Row k of a [K][n] array as a wave-uniform base pointer: the lane index i then rides in ONE 32-bit
@@ -830,6 +830,8 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
         prev_meal = o.meal;
         if (c.bg_trace) c.bg_trace[(c.trace_row + s) * a.n + i] = o.bg;
         if (c.cgm_trace) c.cgm_trace[(c.trace_row + s) * a.n + i] = o.cgm;
+        if (c.cho_trace) c.cho_trace[(c.trace_row + s) * a.n + i] = o.meal;
+        if (c.ins_trace) c.ins_trace[(c.trace_row + s) * a.n + i] = o.ins;
         pre_prev_cgm = e.prev_cgm;
         e.prev_cgm = o.cgm;                      // CGM history advances every step
         if (c.sum_risk) { T l, h, r; risk_index1<MATH>(o.bg, l, h, r); sum_risk += r; }
@@ -1650,7 +1652,8 @@ static PidArgs<T> make_pid(const t1d_pid* p, int n_steps)
     c.min_bg = (T*)p->min_bg; c.max_bg = (T*)p->max_bg; c.n_low = p->n_low; c.n_high = p->n_high;
     c.n_steps = n_steps;
     c.kind = 0; c.bb_basal = nullptr; c.bb_cr = nullptr; c.bb_cf = nullptr; c.bb_prev_meal = nullptr;
-    c.bg_trace = (T*)p->bg_trace; c.cgm_trace = (T*)p->cgm_trace; c.trace_row = p->trace_row;
+    c.bg_trace = (T*)p->bg_trace; c.cgm_trace = (T*)p->cgm_trace; c.cho_trace = (T*)p->cho_trace; c.ins_trace = (T*)p->insulin_trace;
+    c.trace_row = p->trace_row;
     return c;
 }
 
@@ -1663,7 +1666,8 @@ static PidArgs<T> make_bb(const t1d_bb* p, int n_steps)
     c.min_bg = (T*)p->min_bg; c.max_bg = (T*)p->max_bg; c.n_low = p->n_low; c.n_high = p->n_high;
     c.n_steps = n_steps;
     c.kind = 1; c.bb_basal = (const T*)p->basal; c.bb_cr = (const T*)p->cr; c.bb_cf = (const T*)p->cf; c.bb_prev_meal = (T*)p->prev_meal;
-    c.bg_trace = (T*)p->bg_trace; c.cgm_trace = (T*)p->cgm_trace; c.trace_row = p->trace_row;
+    c.bg_trace = (T*)p->bg_trace; c.cgm_trace = (T*)p->cgm_trace; c.cho_trace = (T*)p->cho_trace; c.ins_trace = (T*)p->insulin_trace;
+    c.trace_row = p->trace_row;
     return c;
 }
 

@@ -217,13 +217,30 @@ def test_rollout_bb_config1_matches_reference_host_loop_and_oracle(golden):
     stt = None
     stats = {"n_high": torch.zeros(n, dtype=torch.int32, device=eb.device),
              "max_bg": torch.zeros(n, dtype=torch.float64, device=eb.device)}
+    tr = eb.new_trace(K)
     for chunk in (1, 9, 170, 300):
-        stt = eb.rollout_bb(chunk, bb_state=stt, stats=stats)
+        stt = eb.rollout_bb(chunk, bb_state=stt, stats=stats, trace=tr)
     for k in ("x", "t", "cgm", "bg", "last_cgm", "prev_cgm", "reward", "planned", "meal", "insulin"):
         assert torch.allclose(getattr(ea, k).double(), getattr(eb, k).double(), rtol=0, atol=1e-9), k
     assert torch.allclose(stt["prev_meal"], meal, atol=1e-12)
     assert np.array_equal(stats["n_high"].cpu().numpy(), (bg_a > 180).sum(0))
     assert np.abs(stats["max_bg"].cpu().numpy() - bg_a.max(0)).max() < 1e-9
+    # (b') the device-resident history as the reference's show_history() table / per-patient CSV
+    import pandas as pd
+    from datetime import datetime
+    from simglucose_amd.analysis import report
+    df = report.history_frame(tr, 0, datetime(2018, 1, 1, 0, 0, 0), st)
+    ref = pd.read_csv(os.path.join(os.path.dirname(__file__), "golden", "g6_config1_adult001_bb.csv"), index_col="Time", parse_dates=True)
+    assert list(df.columns) == list(ref.columns) and df.index.name == "Time" and len(df) == len(ref) == K + 1
+    assert (df.index == ref.index).all()
+    for col, tol in (("BG", 1e-3), ("CGM", 1e-3), ("LBGI", 2e-3), ("HBGI", 2e-3), ("Risk", 2e-3), ("CHO", 1e-12), ("insulin", 1e-9)):
+        assert np.nanmax(np.abs(df[col].values - ref[col].values)) < tol, col
+        assert np.array_equal(np.isnan(df[col].values), np.isnan(ref[col].values)), col
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        files = report.save_histories(tr, [0, 16], ["adult#001", names[1]], tmp, datetime(2018, 1, 1), st)
+        back = pd.read_csv(files[0], index_col="Time", parse_dates=True)
+        assert np.nanmax(np.abs(back["BG"].values - df["BG"].values)) < 1e-12 and os.path.basename(files[1]) == names[1] + ".csv"
     # (c) the oracle's closed loop with the same scheme, every patient of the batch
     for j, nm in enumerate(names):
         hist, a = O.closed_loop(nm, "Dexcom", 1, 1, K, lambda cgm, info, nm=nm: O.bb_policy(nm, info["meal"], cgm, info["sample_time"]),
