@@ -431,19 +431,30 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
         const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
         return kgut * q1;
     };
-    auto gut_step = [&]() {
+    // One RK4 step of (x0, x1) + the exponential update of x2.  `pre(k)` / `post(k)` run before / after stage k's
+    // gastric-emptying evaluation: the caller issues the LDS reads of a propagator row in pre() and consumes them
+    // in post(), so that their latency hides behind ~50 dependent VALU instructions instead of being waited out.
+    auto gut_step = [&](auto&& pre, auto&& post) {
         p.refresh();
         const T kmax = p(DP_KMAX);
+        pre(0);
         const T F1 = kgutF(g0, g1);
+        post(0, F1);
         const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;
         T y0 = g0 + hh * a0, y1 = g1 + hh * a1;
+        pre(1);
         const T F2 = kgutF(y0, y1);
+        post(1, F2);
         const T b0 = u.d_mg - kmax * y0, b1 = kmax * y0 - F2;
         y0 = g0 + hh * b0; y1 = g1 + hh * b1;
+        pre(2);
         const T F3 = kgutF(y0, y1);
+        post(2, F3);
         const T c0 = u.d_mg - kmax * y0, c1 = kmax * y0 - F3;
         y0 = g0 + h * c0; y1 = g1 + h * c1;
+        pre(3);
         const T F4 = kgutF(y0, y1);
+        post(3, F4);
         const T e0 = u.d_mg - kmax * y0, e1 = kmax * y0 - F4;
         const T F23 = F2 + F3;
         g0 += h6 * (a0 + T(2) * (b0 + c0) + e0);
@@ -451,12 +462,6 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
         const T x2n = p(DP_X2E) * x2 + p(DP_X2WA) * F1 + p(DP_X2WM) * (T(0.5) * F23) + p(DP_X2WB) * F4;
         R += (x2 - x2n) + h6 * (F1 + T(2) * F23 + F4);     // d(x2 + R) = kgut x1 dt
         x2 = x2n;
-    };
-    auto x6_at = [&](int r) -> T {
-        return pr(r) * s6 + pr(r + 1) * s5 + pr(r + 2) * s9 + pr(r + 3) * s10 + pr(r + 4) * s11 + pr(r + 5) * ui + pr(r + 6);
-    };
-    auto x8_at = [&](int r) -> T {
-        return pr(r) * s8 + pr(r + 1) * s7 + pr(r + 2) * s5 + pr(r + 3) * s9 + pr(r + 4) * s10 + pr(r + 5) * s11 + pr(r + 6) * ui;
     };
     auto glucose = [&](T y3, T y4, T y12, T cR, T cD, T X, T XL, T& d3, T& d4, T& d12) {
         p.refresh();
@@ -476,21 +481,28 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
     };
 
     for (int s = 0; s < ns; ++s) {
-        gut_step();
-        const T cRm = p(DP_CF) * R, cDm = p(DP_RATC) * x2;
-        gut_step();
-        const T cRb = p(DP_CF) * R, cDb = p(DP_RATC) * x2;
-        // one propagator row at a time: 28 table reads in flight at once would cost 56 VGPRs
+        // the propagator rows of this glucose step do not depend on the gut: evaluating them first lets their LDS
+        // reads and FMA chains fill the issue gaps of the gut steps' dependent chains (one row at a time: 28
+        // table reads in flight at once would cost 56 VGPRs)
+        // the four propagator rows of this glucose step ride along the four stages of the first gut step
         const int r = s * 28;
-        __builtin_amdgcn_sched_barrier(0);
-        const T x6m = x6_at(r);
-        __builtin_amdgcn_sched_barrier(0);
-        const T x8m = x8_at(r + 7);
-        __builtin_amdgcn_sched_barrier(0);
-        const T x6b = x6_at(r + 14);
-        __builtin_amdgcn_sched_barrier(0);
-        const T x8b = x8_at(r + 21);
-        __builtin_amdgcn_sched_barrier(0);
+        T cf[7], x6m, x8m, x6b, x8b;
+        auto pre = [&](int k) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) cf[j] = pr(r + 7 * k + j);
+            __builtin_amdgcn_sched_barrier(0);           // the reads are issued here, ahead of the stage
+        };
+        auto post = [&](int k, T F) {
+            // pin: the coefficients are waited for, and the dot product formed, only once this stage's F exists
+            asm volatile("" : "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]) : "v"(F));
+            const T v6 = cf[0] * s6 + cf[1] * s5 + cf[2] * s9 + cf[3] * s10 + cf[4] * s11 + cf[5] * ui + cf[6];
+            const T v8 = cf[0] * s8 + cf[1] * s7 + cf[2] * s5 + cf[3] * s9 + cf[4] * s10 + cf[5] * s11 + cf[6] * ui;
+            if (k == 0) x6m = v6; else if (k == 1) x8m = v8; else if (k == 2) x6b = v6; else x8b = v8;
+        };
+        gut_step(pre, post);
+        const T cRm = p(DP_CF) * R, cDm = p(DP_RATC) * x2;
+        gut_step([](int) {}, [](int, T) {});
+        const T cRb = p(DP_CF) * R, cDb = p(DP_RATC) * x2;
         T k3, k4, k12, a3, a4, a12;
         glucose(z3, x4, x12, cRa, cDa, x6a, x8a, k3, k4, k12);
         a3 = k3; a4 = k4; a12 = k12;
