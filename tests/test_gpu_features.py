@@ -418,6 +418,31 @@ def test_fp32_tracks_fp64():
     assert envs[0].sync() == 0 and envs[1].sync() == 0
 
 
+def test_fp32_single_minute_kernel_tracks_fp64():
+    """The persistent single-minute kernel in fp32 (1-min sensor) against its fp64 instantiation: 6 h with meals."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    n = 3000                                  # not a multiple of 64: the last chunk is partly masked
+    pid = np.arange(n) % 30
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=6 * 60, seed=9, device="cuda:0")
+    envs = []
+    for dt in (torch.float64, torch.float32):
+        e = _mk(patient=pid, sensor="Navigator", dtype=dt, noise="philox", seed=3, n_sub=4)
+        e.set_meals(mt, ma.to(dt))
+        e.reset()
+        envs.append(e)
+    b64 = torch.as_tensor(_basal(pid), device="cuda:0")
+    worst = 0.0
+    for k in range(360):
+        a = b64 * (0.6 + 0.2 * (k % 5))
+        envs[0].step(a); envs[1].step(a.float())
+        if k % 20 == 19:
+            worst = max(worst, float((envs[0].bg - envs[1].bg.double()).abs().max()))
+    assert worst < 0.05, worst
+    assert torch.equal(envs[0].t, envs[1].t) and int(envs[0].t[0]) == 360
+    assert envs[0].sync() == 0 and envs[1].sync() == 0
+
+
 def test_state_dict_roundtrip_and_determinism():
     import torch
     n = 512
