@@ -463,7 +463,9 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
 #define S1_MARK(m) do { } while (0)
 #endif
 constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a CU: T1D_S1_WAVES waves on each of its 4 SIMDs
-template <bool REG, typename T, int STRIDE>
+// EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
+// third risk evaluation drop out of the kernel altogether
+template <bool REG, typename T, int STRIDE, bool EXTRA>
 __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
@@ -558,8 +560,10 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         at(a.t, i) = e.t + 1;
         if (e.next_meal != e.next_meal_loaded) at(row(a.t, a.n, 2), i) = e.next_meal;
         at(row(a.t, a.n, 1), i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
-        if (a.meal) at(a.meal, i) = meal;
-        if (a.insulin) at(a.insulin, i) = insulin;
+        if (EXTRA) {
+            if (a.meal) at(a.meal, i) = meal;
+            if (a.insulin) at(a.insulin, i) = insulin;
+        }
         S1_MARK(2);
         {
             PropLdsS<T, STRIDE> pr{lpr, (int)pid};
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         at(row(a.x, a.n, 17), i) = last_cgm;
         at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
         at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
-        if (a.lbgi || a.hbgi || a.risk) {
+        if (EXTRA && (a.lbgi || a.hbgi || a.risk)) {
             risk_index1<1>(gsub, l, h, r);                                                         // env.py:85
             if (a.lbgi) at(a.lbgi, i) = l;
             if (a.hbgi) at(a.hbgi, i) = h;
@@ -1614,14 +1618,17 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             int blocks = c->pipe_blocks > 0 ? c->pipe_blocks : c->n_cu;       // one workgroup of 4 x T1D_S1_WAVES waves per CU
             if (blocks > nchunks) blocks = nchunks;
             const bool reg = pmode != 0;
-#define T1D_LAUNCH_S1(R, TT, ST) hipLaunchKernelGGL((step1_kernel<R, TT, ST>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
+            const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
+#define T1D_LAUNCH_S1(R, TT, ST, EX) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
+#define T1D_S1_BY_EXTRA(R, TT, ST) do { if (extra) T1D_LAUNCH_S1(R, TT, ST, true); else T1D_LAUNCH_S1(R, TT, ST, false); } while (0)
             if (b->dtype == T1D_F64) {
-                if (stride == 32) { if (reg) T1D_LAUNCH_S1(true, double, 32); else T1D_LAUNCH_S1(false, double, 32); }
-                else { if (reg) T1D_LAUNCH_S1(true, double, 64); else T1D_LAUNCH_S1(false, double, 64); }
+                if (stride == 32) { if (reg) T1D_S1_BY_EXTRA(true, double, 32); else T1D_S1_BY_EXTRA(false, double, 32); }
+                else { if (reg) T1D_S1_BY_EXTRA(true, double, 64); else T1D_S1_BY_EXTRA(false, double, 64); }
             } else {
-                if (stride == 32) { if (reg) T1D_LAUNCH_S1(true, float, 32); else T1D_LAUNCH_S1(false, float, 32); }
-                else { if (reg) T1D_LAUNCH_S1(true, float, 64); else T1D_LAUNCH_S1(false, float, 64); }
+                if (stride == 32) { if (reg) T1D_S1_BY_EXTRA(true, float, 32); else T1D_S1_BY_EXTRA(false, float, 32); }
+                else { if (reg) T1D_S1_BY_EXTRA(true, float, 64); else T1D_S1_BY_EXTRA(false, float, 64); }
             }
+#undef T1D_S1_BY_EXTRA
 #undef T1D_LAUNCH_S1
             T1D_HIP(hipGetLastError());
             return T1D_OK;
