@@ -116,7 +116,8 @@ typedef struct t1d_batch {
     int32_t* next_meal;       /* [n] minute of the next meal-table entry (INT32_MAX = none), maintained by
                                  t1d_reset/t1d_step so the common minute needs no table access.  NULL = the
                                  table row at the cursor is read every minute instead */
-    void* last_cgm;           /* [n] sensor zero-order hold (cgm.py:32-36) */
+    void* last_cgm;           /* [n] sensor zero-order hold (cgm.py:32-36); never read with a 1-minute sensor, and then
+                               * not maintained by one-minute launches (the observation is in cgm / prev_cgm) */
     void* ar_e;               /* [n] AR(1) noise state      (noise_gen.py:86-88) */
     void* pts;                /* [26][n] CGM-noise spline of the current 150-min block: rows 0-10 the Johnson-SU
                                  points, 11-21 their knot second derivatives, 22-25 the current 15-min interval */

@@ -559,7 +559,10 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         if (e.lf != lf0) at(row(a.x, a.n, 15), i) = e.lf;
         at(a.t, i) = e.t + 1;
         if (e.next_meal != e.next_meal_loaded) at(row(a.t, a.n, 2), i) = e.next_meal;
-        at(row(a.t, a.n, 1), i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+        {   // patient id, eating flag, meal cursor: changes when a meal starts, ends or fires
+            const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+            if (meta1 != meta) at(row(a.t, a.n, 1), i) = meta1;
+        }
         if (EXTRA) {
             if (a.meal) at(a.meal, i) = meal;
             if (a.insulin) at(a.insulin, i) = insulin;
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
             c = c > vmin ? c : vmin;
             c = c < vmax ? c : vmax;
             last_cgm = c;
-            at(row(a.x, a.n, 16), i) = c;
+            if (a.sen.st != 1) at(row(a.x, a.n, 16), i) = c;      // the zero-order hold is dead state with a 1-minute sensor
         }
         T l, h, r, rc = T(0);
         if (!(a.flags & 0x100)) risk_index1<1>(last_cgm, l, h, rc);
