@@ -159,7 +159,7 @@ def main():
                                    % (n, a.sensor, minutes, integ, a.n_sub),
                        "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": ("t1d::step1_kernel<true, %s, 32>" if integ == "split" and minutes == 1 else "t1d::step_kernel<%d, %s, false>" % (4 if integ == "split" else 3, "%s")) % ("double" if a.dtype == "f64" else "float"),
+                         "traffic": traffic, "kernel": ("t1d::step1_kernel<true, %s, 32, false>" if integ == "split" and minutes == 1 else "t1d::step_kernel<%d, %s, false>" % (4 if integ == "split" else 3, "%s")) % ("double" if a.dtype == "f64" else "float"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
