@@ -231,8 +231,10 @@ class OracleEnv:
     OUT_KEYS = ("cgm", "bg", "reward", "lbgi", "hbgi", "risk", "meal", "insulin", "cgm_hist0")
 
     def __init__(self, patient_idx, sensor="Dexcom", pump="Insulet", normals=None, n_draws_max=256,
-                 integrator="rk4", n_sub=4, beta=DOPRI_BETA, sensor_row_override=None):
+                 integrator="rk4", n_sub=4, beta=DOPRI_BETA, sensor_row_override=None, ptab_override=None):
         self.names, self.ptab = patient_table()
+        if ptab_override is not None:
+            self.ptab = np.ascontiguousarray(ptab_override, dtype=np.float64)
         self.pid = np.ascontiguousarray(patient_idx, dtype=np.int32)
         n = self.n = len(self.pid)
         self.sensor = np.array(sensor_row_override if sensor_row_override is not None else sensor_row(sensor))

@@ -344,6 +344,41 @@ def test_outcome_statistics_match_reference_report(golden, dtype):
     assert envs[0].sync() == 0 and envs[1].sync() == 0
 
 
+@pytest.mark.parametrize("sensor", ["Navigator", "Dexcom"])
+def test_custom_patient_table_with_more_than_32_patients(sensor):
+    """A caller-supplied table of 44 patients (the 30 of the reference + perturbed copies): the single-minute kernel
+    then runs its 64-patient LDS layout, the generic kernels a 44-column propagator table; both against the oracle
+    on the same table."""
+    import torch
+    from simglucose_amd import params
+    from oracle import t1d_oracle as O
+    names, tab = params.patient_table()
+    rs = np.random.RandomState(44)
+    extra = tab[rs.randint(0, 30, 14)].copy()
+    for c in ("kabs", "kmax", "kp2", "k1", "k2", "m1", "m30", "ka2", "ksc", "p2u", "ki", "Vmx"):
+        extra[:, params.P_COL[c]] *= rs.uniform(0.85, 1.15, 14)
+    big = np.ascontiguousarray(np.vstack([tab, extra]))
+    n = 88
+    pid = np.arange(n) % 44
+    z = rs.randn(20, n)
+    e = _mk(patient=pid, patient_table=big, sensor=sensor, noise="host", normals=z, n_sub=4)
+    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="split", n_sub=4, ptab_override=big)
+    o0, r0 = e.reset(), orc.reset()
+    assert np.abs(o0.cpu().numpy() - r0["cgm"]).max() < 1e-9
+    st = int(e.minutes_per_step)
+    b = big[pid, params.P_COL["u2ss"]] * big[pid, params.P_COL["BW"]] / 6000.0
+    for k in range(40):
+        cho = np.zeros((st, n))
+        if k == 4:
+            cho[0] = 55.0
+        a = b * (0.4 + 0.4 * (k % 4))
+        e.step(torch.as_tensor(a, device=e.device), cho=cho)
+        r = orc.step(a, None, cho)
+        assert np.abs(e.bg.cpu().numpy() - r["bg"]).max() < 1e-8, k
+        assert np.abs(e.cgm.cpu().numpy() - r["cgm"]).max() < 1e-8, k
+    assert e.sync() == 0
+
+
 def test_random_meal_tables_match_reference_generator_statistics():
     """t1d_random_meals against the reference's RandomScenario.create_scenario as restated (and
     pinned by fixture G9) in the oracle: structure of the tables exactly, distributions per meal window within
