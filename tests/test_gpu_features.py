@@ -379,6 +379,37 @@ def test_custom_patient_table_with_more_than_32_patients(sensor):
     assert e.sync() == 0
 
 
+def test_c_abi_argument_errors_are_reported_not_executed():
+    """Error behaviour at the C ABI on a live device: bad arguments come back as negative codes with a message
+    (the Python layer raises T1DError / ValueError) and leave the env usable."""
+    import ctypes as C
+    import torch
+    from simglucose_amd import _lib
+    e = _mk(patient="adult#001", n_envs=130, sensor="Dexcom", n_sub=4)
+    e.reset()
+    a = torch.full((130,), 0.01, dtype=torch.float64, device=e.device)
+    L = e._L
+    for minutes, n_sub in ((0, 4), (3, 0), (100001, 4), (3, 5000)):
+        assert L.t1d_step(e._ctx, C.byref(e._b), minutes, n_sub, None) == -1 and b"t1d_step" in L.t1d_last_error()
+    e._b.basal = None
+    assert L.t1d_step(e._ctx, C.byref(e._b), 3, 4, None) == -1 and b"basal" in L.t1d_last_error()
+    with pytest.raises(ValueError):
+        e.step(a, cho=np.zeros((2, 130)))                       # cho must be [minutes, n]
+    with pytest.raises(ValueError):
+        e.reset(x0=np.zeros((12, 130)))
+    with pytest.raises(_lib.T1DError):
+        e.set_option("no_such_option", 1)
+    with pytest.raises(_lib.T1DError):
+        e.set_option("math", 7)
+    bad = _lib.Bb()
+    assert L.t1d_rollout_bb(e._ctx, C.byref(e._b), C.byref(bad), 4, 3, 4, None) == -1
+    out = _lib.Outcome()
+    assert L.t1d_outcome_stats(0, 0, 130, 0, C.c_void_p(e.bg.data_ptr()), C.byref(out), None) == -1
+    assert L.t1d_random_meals(0, 1, 0, 130, 0, 0, None, 0, C.c_void_p(e.t.data_ptr()), C.c_void_p(e.bg.data_ptr()), None) == -1
+    e.step(a)                                                    # still works
+    assert e.sync() == 0 and bool(torch.isfinite(e.bg).all())
+
+
 def test_random_meal_tables_match_reference_generator_statistics():
     """t1d_random_meals against the reference's RandomScenario.create_scenario as restated (and
     pinned by fixture G9) in the oracle: structure of the tables exactly, distributions per meal window within
