@@ -221,12 +221,31 @@ __device__ T1D_REFILL_ATTR void noise_refill(T* __restrict__ pts, const T* __res
 // step kernel), which keeps the rarely-run refill code -- Philox, Box-Muller, ten Johnson transforms, the
 // 11x11 spline operator -- and above all its registers out of the step kernel: with it inlined the fp64
 // step kernel needs 256 VGPRs + scratch, without it 180-220 and no scratch (117 vs 140 us at 1 Mi envs).
+// x / d and x % d for x >= 0 and a wave-uniform d.  An integer division by a run-time divisor costs ~20 VALU
+// instructions, three of them quarter-rate; the sensor grid only ever divides by sample_time (1, 3, 5 minutes
+// for the reference's sensors) and by samples-per-block 150 / sample_time, so those take a uniform branch to a
+// compile-time divisor (a multiply-high and a shift) and anything else the general path.
+__device__ __forceinline__ void divmod_uniform(int x, int d, int& q, int& r)
+{
+    switch (d) {
+        case 1: q = x; r = 0; return;
+        case 3: q = x / 3; break;
+        case 5: q = x / 5; break;
+        case 30: q = x / 30; break;
+        case 50: q = x / 50; break;
+        case 150: q = x / 150; break;
+        default: q = x / d; break;
+    }
+    r = x - q * d;
+}
+
 template <bool REFILL, typename T>
 __device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, T (&cur)[4])
 {
     const int64_t n = a.n;
     const int st = a.sen.st;
-    const int j = s % a.S, b = s / a.S;
+    int j, b;
+    divmod_uniform(s, a.S, b, j);
     const int tau = (j + 1) * st;
     const int m = tau / 15 < 9 ? tau / 15 : 9;
     const int mprev = (tau - st) / 15 < 9 ? (tau - st) / 15 : 9;
@@ -253,8 +272,10 @@ template <bool REFILL, typename T>
 __device__ __forceinline__ T measure_noise(const KArgs<T>& a, unsigned i, Env<T>& e, bool& due)
 {
     const int t1 = e.t + 1;
-    due = (t1 % a.sen.st) == 0;
-    return due ? noise_sample<REFILL>(a, i, 1 + t1 / a.sen.st, e.cur) : T(0);
+    int q, r;
+    divmod_uniform(t1, a.sen.st, q, r);
+    due = r == 0;
+    return due ? noise_sample<REFILL>(a, i, 1 + q, e.cur) : T(0);
 }
 template <typename T>
 __device__ __forceinline__ T measure_apply(const KArgs<T>& a, Env<T>& e, T gsub, T noise, bool due)
@@ -798,11 +819,13 @@ __global__ __launch_bounds__(kBlock) void refill_kernel(const KArgs<T> a)
     const int t = at(a.t, i);
     for (int m = 1; m <= a.minutes; ++m) {
         const int t1 = t + m;
-        if (t1 % a.sen.st != 0) continue;
-        const int s = 1 + t1 / a.sen.st;
-        if (s % a.S != 0) continue;
+        int q, r, blk, j;
+        divmod_uniform(t1, a.sen.st, q, r);
+        if (r != 0) continue;
+        divmod_uniform(1 + q, a.S, blk, j);
+        if (j != 0) continue;
         T e = at(a.ar_e, i);
-        noise_refill<T>(a.pts, a.normals, a.minv, a.episode, a.status, a.n, i, a.env_offset, a.seed, a.n_normals, s / a.S, a.sen, &e);
+        noise_refill<T>(a.pts, a.normals, a.minv, a.episode, a.status, a.n, i, a.env_offset, a.seed, a.n_normals, blk, a.sen, &e);
         at(a.ar_e, i) = e;
     }
 }

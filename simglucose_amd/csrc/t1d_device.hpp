@@ -614,7 +614,7 @@ __device__ __forceinline__ T pump_quantise(T amount, T inc, T lo, T hi)
 {
     T v = amount * T(6000);
     v = t_rint(v / inc) * inc;          // IEEE division: decides which increment an exact tie rounds to
-    v = v / T(6000);
+    v = fdiv(v, T(6000));               // <= 1 ulp: scaling back to U/min decides nothing
     v = v < hi ? v : hi;
     v = v > lo ? v : lo;
     return v;
