@@ -379,6 +379,31 @@ def test_custom_patient_table_with_more_than_32_patients(sensor):
     assert e.sync() == 0
 
 
+@pytest.mark.parametrize("pump", ["Insulet", "Cozmo"])
+@pytest.mark.parametrize("sensor", ["Navigator", "Dexcom"])
+def test_pump_quantiser_in_kernel_matches_reference(golden, pump, sensor):
+    """G3: the reference's InsulinPump.basal/.bolus on 364 amounts (negative, ties at half increments, beyond the
+    limits) through the step kernels' quantiser (single-minute and generic kernel): the insulin output is the
+    sum of the two quantised rates; which increment a tie rounds to must agree exactly, the value to 1 ulp."""
+    import torch
+    g = golden("g3_pump.npz")
+    amt = g["amount"]
+    n = len(amt)
+    e = _mk(patient="adult#001", n_envs=n, sensor=sensor, pump=pump, n_sub=4)
+    e.reset()
+    a = torch.as_tensor(amt, dtype=torch.float64, device=e.device)
+    e.step(a, torch.zeros_like(a))
+    want_b = g["basal_" + pump] + np.maximum(float(e.pump_row[0]), 0.0)          # + pump.bolus(0)
+    got = e.insulin.cpu().numpy()
+    ulps = lambda x, y: np.max(np.abs(x - y) / np.spacing(np.maximum(np.abs(y), 1e-300)))
+    assert ulps(got, want_b) <= 4, ulps(got, want_b)                             # fast reciprocal + mean over the step
+    e.step(torch.zeros_like(a), a)
+    want = g["bolus_" + pump] + float(np.clip(0.0, e.pump_row[3], e.pump_row[4]))
+    got = e.insulin.cpu().numpy()
+    assert ulps(got, want) <= 4, ulps(got, want)
+    assert e.sync(raise_on_status=False) in (0, 2)                               # absurd doses may drive a state non-finite
+
+
 def test_c_abi_argument_errors_are_reported_not_executed():
     """Error behaviour at the C ABI on a live device: bad arguments come back as negative codes with a message
     (the Python layer raises T1DError / ValueError) and leave the env usable."""
