@@ -579,6 +579,47 @@ def test_full_batch_properties_1m_envs():
     assert e.sync() == 0 and e2.sync() == 0
 
 
+def test_full_size_24h_run_sampled_envs_match_oracle():
+    """The headline workload end to end at BASELINE's full size: 1 048 576 envs, 24 h of one-minute steps with a
+    random-action policy, random meal tables and Philox CGM noise (1 440 launches of the single-minute kernel).
+    300 envs sampled across the batch (every patient, first and last workgroups, wave edges) are replayed on the
+    oracle with the very normals, meals and actions the kernel used and must agree to 1e-8 mg/dL throughout."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    from oracle import t1d_oracle as O
+    n, K = 1 << 20, 1440
+    pid = np.arange(n) % 30
+    e = _mk(patient=pid, sensor="Navigator", noise="philox", seed=77, n_sub=4, extra_outputs=False)
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=0, seed=5, device=e.device)
+    e.set_meals(mt, ma)
+    rs = np.random.RandomState(1)
+    sample = np.unique(np.concatenate([np.arange(0, 130), np.arange(n - 130, n), rs.randint(0, n, 60)]))[:300]
+    z = e.philox_normals(1 + 10 * (1 + K // 150), draw0=0, episode=1)[:, torch.as_tensor(sample, device=e.device)].cpu().numpy()
+    t_s, a_s = mt[:, sample].cpu().numpy().astype(np.int64), ma[:, sample].cpu().numpy()
+    cho = np.zeros((K, len(sample)))
+    for j in range(len(sample)):
+        for tt, aa in zip(t_s[:, j], a_s[:, j]):
+            if tt < K:
+                cho[tt, j] = aa
+    b0 = torch.as_tensor(_basal(pid), device=e.device)
+    g = torch.Generator(device=e.device); g.manual_seed(3)
+    pool = [(b0 * 2.0 * torch.rand(n, generator=g, device=e.device, dtype=torch.float64)).contiguous() for _ in range(8)]
+    pool_s = [p[torch.as_tensor(sample, device=e.device)].cpu().numpy() for p in pool]
+    orc = O.OracleEnv(pid[sample], sensor="Navigator", normals=z, integrator="split", n_sub=4)
+    sidx = torch.as_tensor(sample, device=e.device)
+    o0, r0 = e.reset(), orc.reset()
+    assert np.abs(o0[sidx].cpu().numpy() - r0["cgm"]).max() < 1e-9
+    worst = 0.0
+    for k in range(K):
+        e.step(pool[k % 8])
+        r = orc.step(pool_s[k % 8], None, cho[k:k + 1])
+        if k % 16 == 15 or k == K - 1:
+            worst = max(worst, np.abs(e.bg[sidx].cpu().numpy() - r["bg"]).max(), np.abs(e.cgm[sidx].cpu().numpy() - r["cgm"]).max())
+    assert worst < 1e-8, worst
+    assert np.abs(e.x[:, sidx].cpu().numpy() - orc.x).max() < 1e-6
+    assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K == int(e.t.max())
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("params", ["lds", "reg", "scalar"])
 def test_pipelined_kernel_matches_tile_kernel_and_oracle(dtype, params):
