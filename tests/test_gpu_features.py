@@ -583,7 +583,8 @@ def test_full_size_24h_run_sampled_envs_match_oracle():
     """The headline workload end to end at BASELINE's full size: 1 048 576 envs, 24 h of one-minute steps with a
     random-action policy, random meal tables and Philox CGM noise (1 440 launches of the single-minute kernel).
     300 envs sampled across the batch (every patient, first and last workgroups, wave edges) are replayed on the
-    oracle with the very normals, meals and actions the kernel used and must agree to 1e-8 mg/dL throughout."""
+    oracle with the very normals, meals and actions the kernel used and must agree to 1e-8 mg/dL throughout; the
+    distance to the oracle's SciPy-faithful DOPRI5 path (pinned to the reference to 1e-9) is bounded as measured."""
     import torch
     from simglucose_amd import scenario_batch as sb
     from oracle import t1d_oracle as O
@@ -606,16 +607,32 @@ def test_full_size_24h_run_sampled_envs_match_oracle():
     pool = [(b0 * 2.0 * torch.rand(n, generator=g, device=e.device, dtype=torch.float64)).contiguous() for _ in range(8)]
     pool_s = [p[torch.as_tensor(sample, device=e.device)].cpu().numpy() for p in pool]
     orc = O.OracleEnv(pid[sample], sensor="Navigator", normals=z, integrator="split", n_sub=4)
+    ref = O.OracleEnv(pid[sample], sensor="Navigator", normals=z, integrator="dopri")      # SciPy's DOPRI5 as the reference drives it
     sidx = torch.as_tensor(sample, device=e.device)
     o0, r0 = e.reset(), orc.reset()
+    ref.reset()
     assert np.abs(o0[sidx].cpu().numpy() - r0["cgm"]).max() < 1e-9
-    worst = 0.0
+    worst, worst_scipy = 0.0, 0.0
+    alive = np.ones(len(sample), bool)                       # compared while BG stays out of the clamp regime
+    worst_env = np.zeros(len(sample))
     for k in range(K):
         e.step(pool[k % 8])
         r = orc.step(pool_s[k % 8], None, cho[k:k + 1])
+        rr = ref.step(pool_s[k % 8], None, cho[k:k + 1])
+        alive &= rr["bg"] >= 20.0
         if k % 16 == 15 or k == K - 1:
-            worst = max(worst, np.abs(e.bg[sidx].cpu().numpy() - r["bg"]).max(), np.abs(e.cgm[sidx].cpu().numpy() - r["cgm"]).max())
+            bg = e.bg[sidx].cpu().numpy()
+            worst = max(worst, np.abs(bg - r["bg"]).max(), np.abs(e.cgm[sidx].cpu().numpy() - r["cgm"]).max())
+            if alive.any():
+                worst_scipy = max(worst_scipy, np.abs(bg - rr["bg"])[alive].max())
+                worst_env = np.maximum(worst_env, np.where(alive, np.abs(bg - rr["bg"]), 0.0))
     assert worst < 1e-8, worst
+    # Against SciPy's adaptive solution the fixed-step schemes hold 1e-3 on the reference's own scenarios (fixtures
+    # G2/G5/G6/G10, upstream CSV); on random six-meal days with meals up to ~110 g about one env-day in twelve goes
+    # beyond it (worst ~6e-3, steep gastric-emptying patients after large meals; SciPy's default tolerance is itself
+    # up to 2.6e-3 from a tight solve there) -- DESIGN.md section 4.  n_sub = 8 is the setting for those.
+    assert alive.sum() > 250 and worst_scipy < 1e-2, (alive.sum(), worst_scipy)
+    assert (worst_env <= 1e-3).mean() > 0.85 and np.median(worst_env) < 4e-4, ((worst_env <= 1e-3).mean(), np.median(worst_env))
     assert np.abs(e.x[:, sidx].cpu().numpy() - orc.x).max() < 1e-6
     assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K == int(e.t.max())
 
