@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--n-sub", type=int, default=4)
     ap.add_argument("--sensor", default="Navigator")
     ap.add_argument("--integrator", choices=("auto", "rk4", "split"), default="auto")
+    ap.add_argument("--adaptive-gut", action="store_true", help="split integrator with half-size gut steps across fast gastric-emptying transitions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
@@ -96,6 +97,9 @@ def main():
                            env_offset=rank * n, noise="philox", extra_outputs=False)
     env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
     integ = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else "split"
+    if a.adaptive_gut and integ == "split":
+        env.set_option("adaptive_gut", 1)
+        integ = "split_adaptive"
     days = 1 + (a.steps + a.warmup) * env.minutes_per_step // 1440
     mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=0, seed=1000, device=dev, dtype=dt, env_offset=rank * n)
     env.set_meals(mt, ma)
@@ -159,7 +163,9 @@ def main():
                                    % (n, a.sensor, minutes, integ, a.n_sub),
                        "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": ("t1d::step1_kernel<true, %s, 32, false>" if integ == "split" and minutes == 1 else "t1d::step_kernel<%d, %s, false>" % (4 if integ == "split" else 3, "%s")) % ("double" if a.dtype == "f64" else "float"),
+                         "traffic": traffic, "kernel": ({"split": "t1d::step1_kernel<true, %s, 32, false, false>", "split_adaptive": "t1d::step1_kernel<false, %s, 32, false, true>"}[integ]
+                                    if integ != "rk4" and minutes == 1 else
+                                    "t1d::step_kernel<%d, %s, false>" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], "%s")) % ("double" if a.dtype == "f64" else "float"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),

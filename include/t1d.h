@@ -221,13 +221,18 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * (:151-173,201-202) -- which needs math = 1 and n_sub in {2, 4, 6, 8}; -1 (default) = split whenever
  * those hold, classical RK4 otherwise.  Both meet 1e-3 mg/dL against scipy at n_sub = 4 (same error:
  * it is set by the gastric-emptying term, which both integrate alike); the persistent kernel
- * ("pipeline") integrates with classical RK4 only. */
+ * ("pipeline") integrates with classical RK4 only.
+ * "adaptive_gut": 1 = the split integrator takes two gut steps of half the size in the minutes in which an
+ * argument of the gastric-emptying tanh pair (t1dpatient.py:138-140) moves fast through its transition (< 1 % of
+ * the env-minutes of a RandomScenario day: steep patients after large meals), which is where fixed steps lose
+ * accuracy; the error against a tight solve then equals that of n_sub doubled.  Default 0. */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Host-only helper (no device needed): the tables of the split integrator for one patient row
  * (T1D_P_* order, n_cols == T1D_P_NCOLS) and n_sub in {2, 4, 6, 8}: 14 n_sub + 21 entries of the
  * insulin propagator Phi(k/n_sub) (layout in simglucose_amd/csrc/t1d_device.hpp) followed by the four
- * weights E, wa, wm, wb of the exponential gut update; out_len >= 14 n_sub + 25.  What t1d_step
+ * weights E, wa, wm, wb of the exponential gut update for h = 1/n_sub and the same four for h/2;
+ * out_len >= 14 n_sub + 29.  What t1d_step
  * uploads; exposed so that the tables can be checked against an independent matrix exponential. */
 /* SimObj.simulate (sim_engine.py:29-39) with BBController for n_steps env.steps in ONE launch: per step
  * basal = bb.basal; bolus = (prev_meal*sample_time/CR + (CGM > 150)*(CGM - target)/CF) / sample_time if

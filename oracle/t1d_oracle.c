@@ -173,8 +173,14 @@ void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double 
  *            c = f/BW: the fast rate-of-appearance forcing then enters only through the argument
  *            x3 = z3 + c R(tau), with R, X = x6 and XL = x8 taken at the stage times from the parts above.
  *            The (x >= 0) factors of :167,173,202 are kept.
- * tab: [ng][7][9] Phi(k/ng), k = 1..ng, then E, wa, wm, wb.   Error vs a tight solve is the same as
- * RK4(n_sub = ng) on the whole state (tests/test_oracle_golden.py), at ~60 % of its arithmetic.
+ * tab: [ng][7][9] Phi(k/ng), k = 1..ng, then E, wa, wm, wb for h = 1/ng and E, wa, wm, wb for h = 1/(2 ng).
+ * Error vs a tight solve is the same as RK4(n_sub = ng) on the whole state (tests/test_oracle_golden.py), at
+ * ~60 % of its arithmetic.
+ * adapt != 0 (integrator 4): the gut takes TWO steps of h/2 per step in the minutes in which an argument of the
+ * gastric-emptying tanh pair (t1dpatient.py:138-140) moves fast through its transition -- |change over the
+ * minute| > 4 (predicted from the rate at the start of the minute) while passing within 3 of zero -- which is
+ * where fixed steps lose their accuracy: < 1 % of the env-minutes of a RandomScenario day, and with them the
+ * error against a tight solve drops to that of ng doubled everywhere (tools/random_scenario_error.py).
  * ---------------------------------------------------------------------------------------- */
 static double o_kgut(const double* p, double qsto, double Dbar)
 {
@@ -203,8 +209,10 @@ static void o_glucose_rhs(const double* p, const double* y, double cR, double cR
     dy[0] = d3; dy[1] = d4; dy[2] = d12;
 }
 
+#define T1D_O_ADAPT_NEAR 3.0     /* |tanh argument| below this somewhere in the minute ... */
+#define T1D_O_ADAPT_MOVE 4.0     /* ... while it changes by more than this over the minute */
 int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
-                       double lf, int ng)
+                       double lf, int ng, int adapt)
 {
     if (ng < 2 || ng > 16 || (ng & 1) || !tab) return -1;
     const int ns = ng / 2;
@@ -221,12 +229,25 @@ int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho
             for (int j = 0; j < 9; ++j) a += tab[((k - 1) * 7 + i) * 9 + j] * aug[j];
             S[k][i] = a;
         }
-    const double E = tab[ng * 63], wa = tab[ng * 63 + 1], wm = tab[ng * 63 + 2], wb = tab[ng * 63 + 3];
+    double E = tab[ng * 63], wa = tab[ng * 63 + 1], wm = tab[ng * 63 + 2], wb = tab[ng * 63 + 3];
     /* gut */
-    const double h = 1.0 / (double)ng;
+    double h = 1.0 / (double)ng;
     double g0 = x[0], g1 = x[1], x2 = x[2], Q = 0.0, R[17], X2[17];
     R[0] = 0.0; X2[0] = x2;
-    for (int s = 0; s < ng; ++s) {
+    int mref = 1;
+    if (adapt && Dbar > 0.0) {
+        const double aa = 5.0 / 2.0 / (1.0 - p[T1D_O_B]) / Dbar, cc = 5.0 / 2.0 / p[T1D_O_D] / Dbar;
+        const double q0 = g0 + g1, dq = d - o_kgut(p, q0, Dbar) * g1;          /* d(qsto)/dt at the start of the minute */
+        const double A0 = aa * (q0 - p[T1D_O_B] * Dbar), A1 = A0 + aa * dq;
+        const double C0 = cc * (q0 - p[T1D_O_D] * Dbar), C1 = C0 + cc * dq;
+        const int fa = fabs(A1 - A0) > T1D_O_ADAPT_MOVE && (A0 * A1 <= 0.0 || fmin(fabs(A0), fabs(A1)) < T1D_O_ADAPT_NEAR);
+        const int fc = fabs(C1 - C0) > T1D_O_ADAPT_MOVE && (C0 * C1 <= 0.0 || fmin(fabs(C0), fabs(C1)) < T1D_O_ADAPT_NEAR);
+        if (fa || fc) {
+            mref = 2; h *= 0.5;
+            E = tab[ng * 63 + 4]; wa = tab[ng * 63 + 5]; wm = tab[ng * 63 + 6]; wb = tab[ng * 63 + 7];
+        }
+    }
+    for (int s = 0; s < ng * mref; ++s) {
         double a0, a1, F1, F2, F3, F4, b0, b1, c0, c1, e0, e1, y0, y1;
         F1 = o_kgut(p, g0 + g1, Dbar) * g1; a0 = -kmax * g0 + d; a1 = kmax * g0 - F1;
         y0 = g0 + 0.5 * h * a0; y1 = g1 + 0.5 * h * a1;
@@ -239,7 +260,7 @@ int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho
         g1 += h / 6.0 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
         Q += h / 6.0 * (F1 + 2.0 * F2 + 2.0 * F3 + F4);
         x2 = E * x2 + wa * F1 + wm * (0.5 * (F2 + F3)) + wb * F4;
-        X2[s + 1] = x2; R[s + 1] = x[2] - x2 + Q;
+        if ((s + 1) % mref == 0) { X2[(s + 1) / mref] = x2; R[(s + 1) / mref] = x[2] - x2 + Q; }
     }
     /* glucose */
     const double H = 1.0 / (double)ns;
@@ -520,7 +541,10 @@ int t1d_o_step(t1d_o_batch* b, const double* basal, const double* bolus, const d
                 t1d_o_mr_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub / 1000, n_sub % 1000);
             } else if (integrator == 3) {
                 if (t1d_o_split_minute(p, b->split_tab ? b->split_tab + (size_t)b->pid[i] * b->split_stride : NULL, x,
-                                       to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub) < 0) rc = -1;
+                                       to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub, 0) < 0) rc = -1;
+            } else if (integrator == 4) {
+                if (t1d_o_split_minute(p, b->split_tab ? b->split_tab + (size_t)b->pid[i] * b->split_stride : NULL, x,
+                                       to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub, 1) < 0) rc = -1;
             } else {
                 if (t1d_o_dopri5_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i],
                                         &b->h_carry[i], dopri_beta, (double)b->t[i]) < 0) rc = -1;
@@ -569,6 +593,7 @@ int t1d_o_patient_minute(const double* p, double* x, double* planned, double* la
     *was_eating = (to_eat > 0.0);
     if (integrator == 0) { t1d_o_rk4_minute(p, x, to_eat, insulin, *last_qsto, *last_food, n_sub); return 4 * n_sub; }
     if (integrator == 2) { t1d_o_mr_minute(p, x, to_eat, insulin, *last_qsto, *last_food, n_sub / 1000, n_sub % 1000); return 4 * (n_sub / 1000); }
-    if (integrator == 3) return t1d_o_split_minute(p, split_tab, x, to_eat, insulin, *last_qsto, *last_food, n_sub) < 0 ? -1 : 4 * n_sub;
+    if (integrator == 3 || integrator == 4)
+        return t1d_o_split_minute(p, split_tab, x, to_eat, insulin, *last_qsto, *last_food, n_sub, integrator == 4) < 0 ? -1 : 4 * n_sub;
     return t1d_o_dopri5_minute(p, x, to_eat, insulin, *last_qsto, *last_food, h_carry, dopri_beta, (double)t);
 }

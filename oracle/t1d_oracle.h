@@ -48,7 +48,7 @@ typedef struct {
     int32_t* n_draws;          /* [n] normals consumed */
     double* prev_cgm;          /* [n] CGM_hist[-1] before this step (default reward) */
     const double* split_tab;   /* [n_patients][split_stride] tables of the split scheme (integrator 3) or NULL */
-    int32_t split_stride;      /* = n_sub * 63 + 4 */
+    int32_t split_stride;      /* = n_sub * 63 + 8 */
 } t1d_o_batch;
 
 typedef struct {
@@ -60,7 +60,7 @@ void t1d_o_rhs(const double* p, const double* x, double cho, double ins, double 
 void t1d_o_rk4_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int n_sub);
 void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int ng, int ns);
 int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
-                       double lf, int ng);
+                       double lf, int ng, int adapt);
 int t1d_o_dopri5_minute(const double* p, double* y, double cho, double ins, double lq, double lf,
                         double* h_carry, double beta, double t_start);
 double t1d_o_pump(double amount, double inc, double lo, double hi);

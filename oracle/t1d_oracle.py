@@ -132,7 +132,7 @@ def lib():
         L.t1d_o_pid.argtypes = [_d, _d] + [C.c_double] * 6; L.t1d_o_pid.restype = C.c_double
         L.t1d_o_patient_minute.argtypes = [_d, _d, _d, _d, _d, _u, _d, C.c_int, C.c_double, C.c_double,
                                            C.c_int, C.c_int, C.c_double, _d]
-        L.t1d_o_split_minute.argtypes = [_d, _d, _d, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.t1d_o_split_minute.argtypes = [_d, _d, _d, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         L.t1d_o_split_minute.restype = C.c_int
         L.t1d_o_patient_minute.restype = C.c_int
         _lib = L
@@ -162,7 +162,7 @@ def risk(bg):
 
 DOPRI_BETA = 0.04     # what the Fortran driver uses when scipy hands it beta = 0.0
 # integrator codes of t1d_oracle.c; "mr" = multirate RK4 with n_sub = ng * 1000 + ns
-_INTEG = {"rk4": 0, "dopri": 1, "mr": 2, "split": 3}
+_INTEG = {"rk4": 0, "dopri": 1, "mr": 2, "split": 3, "split_adaptive": 4}
 
 
 def split_tables(ptab, n_sub):
@@ -173,13 +173,9 @@ def split_tables(ptab, n_sub):
     h = 1/n_sub by Gauss-Legendre quadrature of the quadratic interpolant against exp(-kabs (h-s))."""
     from scipy.linalg import expm
     ptab = np.atleast_2d(ptab)
-    out = np.zeros((ptab.shape[0], n_sub * 63 + 4))
+    out = np.zeros((ptab.shape[0], n_sub * 63 + 8))
     gx, gw = np.polynomial.legendre.leggauss(32)
     h = 1.0 / n_sub
-    s = (gx + 1.0) * h / 2.0; w = gw * h / 2.0
-    La = (s - h / 2) * (s - h) / ((0 - h / 2) * (0 - h))
-    Lm = (s - 0) * (s - h) / ((h / 2) * (h / 2 - h))
-    Lb = (s - 0) * (s - h / 2) / (h * (h / 2))
     for r, p in enumerate(ptab):
         g = lambda k: p[IDX[k]]
         A = np.zeros((9, 9))
@@ -192,8 +188,14 @@ def split_tables(ptab, n_sub):
         A[6, 6] = -g("ki"); A[6, 5] = g("ki")                                                         # x8  :187
         for k in range(1, n_sub + 1):
             out[r, (k - 1) * 63:k * 63] = expm(A * (k * h))[:7].ravel()
-        ker = np.exp(-g("kabs") * (h - s))
-        out[r, n_sub * 63:] = (np.exp(-g("kabs") * h), (ker * La * w).sum(), (ker * Lm * w).sum(), (ker * Lb * w).sum())
+        for part, hh in ((0, h), (1, h / 2.0)):               # weights for h and for the refined step h/2 ("split_adaptive")
+            ss = (gx + 1.0) * hh / 2.0; ww = gw * hh / 2.0
+            Lah = (ss - hh / 2) * (ss - hh) / ((0 - hh / 2) * (0 - hh))
+            Lmh = (ss - 0) * (ss - hh) / ((hh / 2) * (hh / 2 - hh))
+            Lbh = (ss - 0) * (ss - hh / 2) / (hh * (hh / 2))
+            ker = np.exp(-g("kabs") * (hh - ss))
+            out[r, n_sub * 63 + 4 * part:n_sub * 63 + 4 * part + 4] = (np.exp(-g("kabs") * hh), (ker * Lah * ww).sum(),
+                                                                      (ker * Lmh * ww).sum(), (ker * Lbh * ww).sum())
     return np.ascontiguousarray(out)
 
 
@@ -210,7 +212,7 @@ class PatientOracle:
 
     def step(self, meal, insulin, integrator="rk4", n_sub=4, beta=DOPRI_BETA):
         tab = None
-        if integrator == "split":
+        if integrator in ("split", "split_adaptive"):
             if n_sub not in self._split:
                 self._split[n_sub] = split_tables(self.p, n_sub)[0]
             tab = _p(self._split[n_sub])
@@ -257,7 +259,7 @@ class OracleEnv:
         for k in range(6): b.pump[k] = self.pump[k]
         for k in ("x", "planned", "last_qsto", "last_food", "h_carry", "last_cgm", "ar_e", "pts", "prev_cgm"):
             setattr(b, k, _p(getattr(self, k)))
-        if integrator == "split":
+        if integrator in ("split", "split_adaptive"):
             self.split_tab = split_tables(self.ptab, n_sub)
             b.split_tab = _p(self.split_tab); b.split_stride = self.split_tab.shape[1]
         b.was_eating = _p(self.was_eating, _u); b.t = _p(self.t, _i)

@@ -402,11 +402,13 @@ __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env
 //         3: fast arithmetic, parameters gathered once per lane into VGPRs (any patient layout)
 //         4: as 3, split integrator (t1d_device.hpp) with the insulin propagator staged in LDS
 //         5: as 1, split integrator
+//         6, 7: as 4, 5 with the adaptive gut refinement
 template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
 template <int VARIANT> struct VariantInfo {
-    static constexpr bool split = VARIANT == 4 || VARIANT == 5;
-    static constexpr bool lds_pars = VARIANT == 0 || VARIANT == 1 || VARIANT == 5;
-    static constexpr bool reg_pars = VARIANT == 3 || VARIANT == 4;
+    static constexpr bool split = VARIANT >= 4 && VARIANT <= 7;
+    static constexpr bool adapt = VARIANT == 6 || VARIANT == 7;
+    static constexpr bool lds_pars = VARIANT == 0 || VARIANT == 1 || VARIANT == 5 || VARIANT == 7;
+    static constexpr bool reg_pars = VARIANT == 3 || VARIANT == 4 || VARIANT == 6;
 };
 extern __shared__ __align__(16) unsigned char t1d_dyn_lds[];
 
@@ -430,15 +432,15 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
     const T rp = prev_risk<MATH>(a, e.prev_cgm);
     StepOut<T> o;
-    if constexpr (VARIANT == 4) {
+    if constexpr (VARIANT == 4 || VARIANT == 6) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
-        PropLds<T> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
-        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL, PropLds<T>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
-    } else if constexpr (VARIANT == 5) {
+        PropLds<T, VI::adapt> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL, PropLds<T, VI::adapt>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
+    } else if constexpr (VARIANT == 5 || VARIANT == 7) {
         ParsLds<T> p{lds, (int)pid};
-        PropLds<T> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
-        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL, PropLds<T>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
+        PropLds<T, VI::adapt> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL, PropLds<T, VI::adapt>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
     } else if constexpr (VARIANT == 2) {
         const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
         if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
 constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a CU: T1D_S1_WAVES waves on each of its 4 SIMDs
 // EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
 // third risk evaluation drop out of the kernel altogether
-template <bool REG, typename T, int STRIDE, bool EXTRA>
+template <bool REG, typename T, int STRIDE, bool EXTRA, bool ADAPT>
 __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
@@ -590,11 +592,15 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         }
         S1_MARK(2);
         {
-            PropLdsS<T, STRIDE> pr{lpr, (int)pid};
+            PropLdsS<T, STRIDE, ADAPT> pr{lpr, (int)pid};
             if (REG) {
                 ParsReg<T> p;
 #pragma unroll
                 for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
+                if (ADAPT) {
+#pragma unroll
+                    for (int k = 0; k < (int)(sizeof(kAdaptPars) / sizeof(int)); ++k) p.v[kAdaptPars[k]] = pl(kAdaptPars[k]);
+                }
                 p.pin_split();
                 if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub);
             } else {
@@ -901,13 +907,13 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void rollout_pid_kernel(const KA
     const uint32_t pid = T1D_META_PID(meta);
     Env<T> e;
     load_env(a, i, meta, e);
-    if constexpr (VARIANT == 4) {
+    if constexpr (VARIANT == 4 || VARIANT == 6) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
-        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
-    } else if constexpr (VARIANT == 5) {
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T, VI::adapt>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+    } else if constexpr (VARIANT == 5 || VARIANT == 7) {
         ParsLds<T> p{lds, (int)pid};
-        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T, VI::adapt>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
     } else if constexpr (VARIANT == 2) {
         const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
         if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
@@ -1169,6 +1175,7 @@ struct t1d_ctx {
     int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
     int split_refill = 1;    // 1 = noise-block refills run in their own kernel ahead of a refill-free step kernel
     int pipe_stagger = 0;    // s_sleep(127) iterations (~3.4 us each) by which the second half of the persistent grid starts late
+    int adaptive_gut = 0;    // 1 = the split integrator halves the gut step in minutes that cross a gastric-emptying transition fast
     int single_minute_kernel = 1;   // 1 = minutes == 1 launches of the split integrator use the persistent early-store kernel
     int integrator = -1;     // 0 = classical RK4 on all 13 states, 1 = split scheme, -1 = split whenever n_sub allows it
     int split_nsub = 0;      // n_sub the split tables on the device were built for (0 = none yet)
@@ -1255,7 +1262,7 @@ static void mat_expm(int n, const double* A, double* E)
 }
 
 // One patient row -> kPropRows(ng) propagator entries (layout: t1d_device.hpp) followed by the four x2
-// weights E, wa, wm, wb.  The insulin sub-system in the order s = (x5, x9, x10, x11, x6, x7, x8, u, 1)
+// weights E, wa, wm, wb for h = 1/ng and the same four for h/2 (adaptive gut refinement).  The insulin sub-system in the order s = (x5, x9, x10, x11, x6, x7, x8, u, 1)
 // (t1dpatient.py:176-198); weights of x2' = -kabs x2 + F (:148) for h = 1/ng from the moments
 // I_k = int_0^1 exp(-z (1 - s)) s^k ds = sum_j (-z)^j k! / (k + j + 1)!,  z = kabs h, of the quadratic
 // through F(0), F(h/2), F(h).
@@ -1296,24 +1303,26 @@ static void split_tables_row(const double* r, int ng, double* out)
     t[12] = Pk[3 * 9 + 2]; t[13] = Pk[3 * 9 + 3]; t[14] = Pk[3 * 9 + 7];
     static const int c7[6] = {5, 0, 1, 2, 3, 7};
     for (int j = 0; j < 6; ++j) t[15 + j] = Pk[5 * 9 + c7[j]];
-    const double z = r[T1D_P_KABS] * h;
-    double I[3];
-    for (int k = 0; k < 3; ++k) {
-        double term = 1.0, sum = 0.0;                    // term = (-z)^j k! / (k + j + 1)!
-        for (int q = 1; q <= k + 1; ++q) term /= (double)q;          // j = 0: k!/(k+1)! = 1/(k+1) -> start from 1/(k+1)!, times k!
-        for (int q = 1; q <= k; ++q) term *= (double)q;
-        for (int j = 0; j < 60; ++j) {
-            sum += term;
-            term *= -z / (double)(k + j + 2);
-            if (std::fabs(term) < 1e-30) break;
+    for (int part = 0; part < 2; ++part) {               // weights for h, then for the refined step h/2
+        const double hh = part ? 0.5 * h : h, z = r[T1D_P_KABS] * hh;
+        double I[3];
+        for (int k = 0; k < 3; ++k) {
+            double term = 1.0, sum = 0.0;                // term = (-z)^j k! / (k + j + 1)!
+            for (int q = 1; q <= k + 1; ++q) term /= (double)q;
+            for (int q = 1; q <= k; ++q) term *= (double)q;
+            for (int j = 0; j < 60; ++j) {
+                sum += term;
+                term *= -z / (double)(k + j + 2);
+                if (std::fabs(term) < 1e-30) break;
+            }
+            I[k] = sum;
         }
-        I[k] = sum;
+        double* w = out + kPropRows(ng) + 4 * part;
+        w[0] = std::exp(-z);
+        w[1] = hh * (2.0 * I[2] - 3.0 * I[1] + I[0]);
+        w[2] = hh * (-4.0 * I[2] + 4.0 * I[1]);
+        w[3] = hh * (2.0 * I[2] - I[1]);
     }
-    double* w = out + kPropRows(ng);
-    w[0] = std::exp(-z);
-    w[1] = h * (2.0 * I[2] - 3.0 * I[1] + I[0]);
-    w[2] = h * (-4.0 * I[2] + 4.0 * I[1]);
-    w[3] = h * (2.0 * I[2] - I[1]);
 }
 
 extern "C" int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len)
@@ -1321,7 +1330,7 @@ extern "C" int t1d_split_tables(const double* patient_row, int n_cols, int n_sub
     if (!patient_row || !out) return fail(T1D_E_INVALID, "t1d_split_tables: NULL argument");
     if (n_cols != T1D_P_NCOLS) return fail(T1D_E_INVALID, "t1d_split_tables: n_cols must be T1D_P_NCOLS (45)");
     if (n_sub < 2 || n_sub > 8 || (n_sub & 1)) return fail(T1D_E_INVALID, "t1d_split_tables: n_sub must be 2, 4, 6 or 8");
-    if (out_len < kPropRows(n_sub) + 4) return fail(T1D_E_INVALID, "t1d_split_tables: out_len < 14 n_sub + 25");
+    if (out_len < kPropRows(n_sub) + 8) return fail(T1D_E_INVALID, "t1d_split_tables: out_len < 14 n_sub + 29");
     split_tables_row(patient_row, n_sub, out);
     return T1D_OK;
 }
@@ -1332,7 +1341,7 @@ static int ensure_split(t1d_ctx* c, int ng)
     if (c->split_nsub == ng) return T1D_OK;
     T1D_HIP(hipDeviceSynchronize());                     // kernels in flight may still be reading the old tables
     const int rows = kPropRows(ng), npp = c->np_pad;
-    std::vector<double> prop((size_t)rows * npp, 0.0), one((size_t)rows + 4);
+    std::vector<double> prop((size_t)rows * npp, 0.0), one((size_t)rows + 8);
     for (int j = 0; j < c->np; ++j) {
         split_tables_row(c->ptab.data() + (size_t)j * T1D_P_NCOLS, ng, one.data());
         for (int k = 0; k < rows; ++k) prop[(size_t)k * npp + j] = one[k];
@@ -1340,6 +1349,10 @@ static int ensure_split(t1d_ctx* c, int ng)
         c->dpar[(size_t)DP_X2WA * kMaxPatients + j] = one[rows + 1];
         c->dpar[(size_t)DP_X2WM * kMaxPatients + j] = one[rows + 2];
         c->dpar[(size_t)DP_X2WB * kMaxPatients + j] = one[rows + 3];
+        c->dpar[(size_t)DP_X2E2 * kMaxPatients + j] = one[rows + 4];
+        c->dpar[(size_t)DP_X2WA2 * kMaxPatients + j] = one[rows + 5];
+        c->dpar[(size_t)DP_X2WM2 * kMaxPatients + j] = one[rows + 6];
+        c->dpar[(size_t)DP_X2WB2 * kMaxPatients + j] = one[rows + 7];
     }
     std::vector<float> propf(prop.begin(), prop.end()), dpf(c->dpar.begin(), c->dpar.end());
     (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); c->d_prop64 = nullptr; c->d_prop32 = nullptr;
@@ -1490,6 +1503,11 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         c->pipeline = (int)value;
         return T1D_OK;
     }
+    if (std::strcmp(name, "adaptive_gut") == 0) {
+        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: adaptive_gut must be 0 or 1");
+        c->adaptive_gut = (int)value;
+        return T1D_OK;
+    }
     if (std::strcmp(name, "single_minute_kernel") == 0) {
         if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: single_minute_kernel must be 0 or 1");
         c->single_minute_kernel = (int)value;
@@ -1605,7 +1623,8 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
         if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_step: split tables exceed 64 KiB of LDS (n_patients x n_sub too large); use integrator 0");
     }
-    const int variant = c->math == 0 ? 0 : (split ? (pmode ? 4 : 5) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
+    const int variant = c->math == 0 ? 0 : (split ? (c->adaptive_gut ? 7 : (pmode ? 4 : 5)) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
+    // (the adaptive scheme always takes its parameters from LDS: with them in VGPRs as well it spills)
 #define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
 #define T1D_LAUNCH_PIPE(V, TT) hipLaunchKernelGGL((step_pipe_kernel<V, TT>), pgrid, dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
     const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
@@ -1643,10 +1662,12 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             const int nchunks = (int)((b->n + 63) / 64);
             int blocks = c->pipe_blocks > 0 ? c->pipe_blocks : c->n_cu;       // one workgroup of 4 x T1D_S1_WAVES waves per CU
             if (blocks > nchunks) blocks = nchunks;
-            const bool reg = pmode != 0;
+            const bool reg = pmode != 0 && !c->adaptive_gut;
             const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
-#define T1D_LAUNCH_S1(R, TT, ST, EX) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
-#define T1D_S1_BY_EXTRA(R, TT, ST) do { if (extra) T1D_LAUNCH_S1(R, TT, ST, true); else T1D_LAUNCH_S1(R, TT, ST, false); } while (0)
+            const bool adapt = c->adaptive_gut != 0;
+#define T1D_LAUNCH_S1(R, TT, ST, EX, AD) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX, AD>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
+#define T1D_S1_BY_EXTRA(R, TT, ST) do { if (adapt) { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, true); else T1D_LAUNCH_S1(R, TT, ST, false, true); } \
+                                        else { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, false); else T1D_LAUNCH_S1(R, TT, ST, false, false); } } while (0)
             if (b->dtype == T1D_F64) {
                 if (stride == 32) { if (reg) T1D_S1_BY_EXTRA(true, double, 32); else T1D_S1_BY_EXTRA(false, double, 32); }
                 else { if (reg) T1D_S1_BY_EXTRA(true, double, 64); else T1D_S1_BY_EXTRA(false, double, 64); }
@@ -1662,12 +1683,15 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     }
 #define T1D_LAUNCH_FAST(V, TT) hipLaunchKernelGGL((step_kernel<V, TT, false>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
 #define T1D_BY_VARIANT(L, TT) do { switch (variant) { case 0: L(0, TT); break; case 1: L(1, TT); break; case 2: L(2, TT); break; \
-                                                      case 3: L(3, TT); break; case 4: L(4, TT); break; default: L(5, TT); break; } } while (0)
+                                                      case 3: L(3, TT); break; case 4: L(4, TT); break; case 5: L(5, TT); break; \
+                                                      default: L(7, TT); break; } } while (0)
     if (split_refill) {          // variant != 0 here
         if (b->dtype == T1D_F64) { switch (variant) { case 1: T1D_LAUNCH_FAST(1, double); break; case 2: T1D_LAUNCH_FAST(2, double); break; case 3: T1D_LAUNCH_FAST(3, double); break;
-                                                      case 4: T1D_LAUNCH_FAST(4, double); break; default: T1D_LAUNCH_FAST(5, double); break; } }
+                                                      case 4: T1D_LAUNCH_FAST(4, double); break; case 5: T1D_LAUNCH_FAST(5, double); break;
+                                                      default: T1D_LAUNCH_FAST(7, double); break; } }
         else { switch (variant) { case 1: T1D_LAUNCH_FAST(1, float); break; case 2: T1D_LAUNCH_FAST(2, float); break; case 3: T1D_LAUNCH_FAST(3, float); break;
-                                  case 4: T1D_LAUNCH_FAST(4, float); break; default: T1D_LAUNCH_FAST(5, float); break; } }
+                                  case 4: T1D_LAUNCH_FAST(4, float); break; case 5: T1D_LAUNCH_FAST(5, float); break;
+                                  default: T1D_LAUNCH_FAST(7, float); break; } }
     } else if (b->dtype == T1D_F64) {
         T1D_BY_VARIANT(T1D_LAUNCH_STEP, double);
     } else {
@@ -1731,12 +1755,13 @@ static int launch_rollout(const char* who, t1d_ctx* c, const t1d_batch* b, int n
         dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
         if (dyn > 65536) return fail(T1D_E_INVALID, std::string(who) + ": split tables exceed 64 KiB of LDS; use integrator 0");
     }
-    const int variant = c->math == 0 ? 0 : (split ? (pmode ? 4 : 5) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
+    const int variant = c->math == 0 ? 0 : (split ? (c->adaptive_gut ? 7 : (pmode ? 4 : 5)) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
 #define T1D_LAUNCH_ROLL(V, TT, MK) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, \
                                                       make_args<TT>(c, b, minutes, n_sub), MK())
 #define T1D_BY_VARIANT(TT, MK) do { switch (variant) { case 0: T1D_LAUNCH_ROLL(0, TT, MK); break; case 1: T1D_LAUNCH_ROLL(1, TT, MK); break; \
                                                        case 2: T1D_LAUNCH_ROLL(2, TT, MK); break; case 3: T1D_LAUNCH_ROLL(3, TT, MK); break; \
-                                                       case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; default: T1D_LAUNCH_ROLL(5, TT, MK); break; } } while (0)
+                                                       case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; case 5: T1D_LAUNCH_ROLL(5, TT, MK); break; \
+                                                       default: T1D_LAUNCH_ROLL(7, TT, MK); break; } } while (0)
     if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, mk64);
     else T1D_BY_VARIANT(float, mk32);
 #undef T1D_BY_VARIANT

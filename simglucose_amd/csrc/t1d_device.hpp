@@ -33,10 +33,11 @@ enum DevPar : int {
     DP_IB, DP_KI, DP_M130 /*m1+m30*/, DP_M2, DP_KA1KD /*ka1+kd*/, DP_KD, DP_KSC, DP_INSC /*6000/BW*/,
     DP_VG, DP_IVI /*1/Vi*/, DP_IVG /*1/Vg*/, DP_DK /*kmax-kmin*/,
     // split integrator only; the four x2 weights depend on n_sub and are rewritten when it changes
-    DP_CF /*f/BW*/, DP_X2E /*exp(-kabs h)*/, DP_X2WA, DP_X2WM, DP_X2WB, DP_COUNT
+    DP_CF /*f/BW*/, DP_X2E /*exp(-kabs h)*/, DP_X2WA, DP_X2WM, DP_X2WB,
+    DP_X2E2 /*the same four for h/2: refined gut steps of the adaptive split scheme*/, DP_X2WA2, DP_X2WM2, DP_X2WB2, DP_COUNT
 };
 constexpr int DP_RK4_COUNT = DP_CF;    // rows the classical-RK4 kernels stage
-constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 43 x 64 x 8 B = 21.5 KiB
+constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 47 x 64 x 8 B = 23.5 KiB
 constexpr int kBlock = 256;
 
 // parameters re-read from LDS at every use; refresh() makes the base opaque so the compiler
@@ -57,6 +58,7 @@ __device__ constexpr int kRhsPars[] = {DP_KMAX, DP_DK, DP_KABS, DP_RATC, DP_KP1,
 // the parameters the split integrator reads inside its loops
 __device__ constexpr int kSplitPars[] = {DP_KMAX, DP_DK, DP_RATC, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2, DP_K1, DP_K2,
                                          DP_VM0, DP_VMX, DP_KM0, DP_KSC, DP_CF, DP_X2E, DP_X2WA, DP_X2WM, DP_X2WB};
+__device__ constexpr int kAdaptPars[] = {DP_X2E2, DP_X2WA2, DP_X2WM2, DP_X2WB2};      // read by refined lanes only
 // parameters gathered once per lane from the (L2-resident) table and held in VGPRs for the launch
 template <typename T> struct ParsReg {
     static constexpr bool kSplitRk4 = true;    // measured: 75 us/minute split vs 79 unsplit, and far fewer spills around the loop
@@ -388,7 +390,7 @@ __device__ __forceinline__ void rk4_substeps_split(P& p, const MinuteIn<T>& u, T
 //                                 x7 <- [x7, x5, x9, x10, x11, u]
 __host__ __device__ constexpr int kPropRows(int ng) { return 14 * ng + 21; }
 
-struct NoProp { static constexpr bool kSplit = false; };
+struct NoProp { static constexpr bool kSplit = false, kAdapt = false; };
 // compact LDS tables with a compile-time row stride (persistent single-minute kernel): every read is one
 // ds_read_b64 with an immediate offset
 template <typename T, int STRIDE> struct ParsLdsS {
@@ -399,21 +401,28 @@ template <typename T, int STRIDE> struct ParsLdsS {
     __device__ __forceinline__ void pin() {}
     __device__ __forceinline__ void pin_split() {}
 };
-template <typename T, int STRIDE> struct PropLdsS {
-    static constexpr bool kSplit = true;
+template <typename T, int STRIDE, bool ADAPT = false> struct PropLdsS {
+    static constexpr bool kSplit = true, kAdapt = ADAPT;
     const T* base; int pid;
     __device__ __forceinline__ T operator()(int r) const { return base[r * STRIDE + pid]; }
 };
 // table in LDS, [rows][stride] with the patient index fastest (different patients -> different banks)
-template <typename T> struct PropLds {
-    static constexpr bool kSplit = true;
+template <typename T, bool ADAPT = false> struct PropLds {
+    static constexpr bool kSplit = true, kAdapt = ADAPT;
     const T* base; int stride; int pid;
     __device__ __forceinline__ T operator()(int r) const { return base[r * stride + pid]; }
 };
 
+// ADAPT: in the minutes in which an argument of the gastric-emptying tanh pair moves fast through its transition
+// (|change over the minute| > 4, predicted from the rate at the start of the minute, while passing within 3 of
+// zero) a lane takes TWO gut steps of h/2 where the others take one of h.  That is where fixed steps lose their
+// accuracy (steep patients after large meals); it concerns < 1 % of the env-minutes of a RandomScenario day and
+// brings the error against a tight solve down to that of n_sub doubled everywhere.  The second half step runs
+// under the flagged lanes' exec mask and is skipped by waves that have none.
 template <typename T, typename P, typename PR>
 __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int ng)
 {
+    constexpr bool ADAPT = PR::kAdapt;
     const int ns = ng >> 1;
     const T h = T(1) / T(ng), hh = T(0.5) * h, h6 = h / T(6);
     const T H = h + h, H6 = H / T(6);                 // glucose step; its half step is h
@@ -434,35 +443,54 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
     // One RK4 step of (x0, x1) + the exponential update of x2.  `pre(k)` / `post(k)` run before / after stage k's
     // gastric-emptying evaluation: the caller issues the LDS reads of a propagator row in pre() and consumes them
     // in post(), so that their latency hides behind ~50 dependent VALU instructions instead of being waited out.
-    auto gut_step = [&](auto&& pre, auto&& post) {
+    // per-lane gut step and x2 weights (ADAPT: halved in flagged minutes; the flag is known after the first stage
+    // of the minute, whose value F1 = kgut x1 at the start does not depend on the step)
+    T gh = h, ghh = hh, gh6 = h6;
+    bool refine = false;
+    auto gut_step = [&](auto&& pre, auto&& post, bool first_of_minute) {
         p.refresh();
         const T kmax = p(DP_KMAX);
         pre(0);
         const T F1 = kgutF(g0, g1);
         post(0, F1);
+        if (ADAPT && first_of_minute) {
+            const T dq = u.d_mg - F1;                                   // d(qsto)/dt at the start of the minute
+            const T q0 = g0 + g1;
+            const T A0 = T(0.5) * u.aa * (q0 - u.bD), dA = T(0.5) * u.aa * dq;      // u.aa, u.cc hold twice the slopes
+            const T C0 = T(0.5) * u.cc * (q0 - u.dD), dC = T(0.5) * u.cc * dq;
+            const T A1 = A0 + dA, C1 = C0 + dC;
+            const bool fa = fabs(dA) > T(4) && (A0 * A1 <= T(0) || t_min(fabs(A0), fabs(A1)) < T(3));
+            const bool fc = fabs(dC) > T(4) && (C0 * C1 <= T(0) || t_min(fabs(C0), fabs(C1)) < T(3));
+            refine = fa || fc;
+            gh = refine ? T(0.5) * h : h; ghh = T(0.5) * gh; gh6 = gh / T(6);
+        }
         const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;
-        T y0 = g0 + hh * a0, y1 = g1 + hh * a1;
+        T y0 = g0 + ghh * a0, y1 = g1 + ghh * a1;
         pre(1);
         const T F2 = kgutF(y0, y1);
         post(1, F2);
         const T b0 = u.d_mg - kmax * y0, b1 = kmax * y0 - F2;
-        y0 = g0 + hh * b0; y1 = g1 + hh * b1;
+        y0 = g0 + ghh * b0; y1 = g1 + ghh * b1;
         pre(2);
         const T F3 = kgutF(y0, y1);
         post(2, F3);
         const T c0 = u.d_mg - kmax * y0, c1 = kmax * y0 - F3;
-        y0 = g0 + h * c0; y1 = g1 + h * c1;
+        y0 = g0 + gh * c0; y1 = g1 + gh * c1;
         pre(3);
         const T F4 = kgutF(y0, y1);
         post(3, F4);
         const T e0 = u.d_mg - kmax * y0, e1 = kmax * y0 - F4;
         const T F23 = F2 + F3;
-        g0 += h6 * (a0 + T(2) * (b0 + c0) + e0);
-        g1 += h6 * (a1 + T(2) * (b1 + c1) + e1);
-        const T x2n = p(DP_X2E) * x2 + p(DP_X2WA) * F1 + p(DP_X2WM) * (T(0.5) * F23) + p(DP_X2WB) * F4;
-        R += (x2 - x2n) + h6 * (F1 + T(2) * F23 + F4);     // d(x2 + R) = kgut x1 dt
+        g0 += gh6 * (a0 + T(2) * (b0 + c0) + e0);
+        g1 += gh6 * (a1 + T(2) * (b1 + c1) + e1);
+        const T wE = (ADAPT && refine) ? p(DP_X2E2) : p(DP_X2E), wA = (ADAPT && refine) ? p(DP_X2WA2) : p(DP_X2WA);
+        const T wM = (ADAPT && refine) ? p(DP_X2WM2) : p(DP_X2WM), wB = (ADAPT && refine) ? p(DP_X2WB2) : p(DP_X2WB);
+        const T x2n = wE * x2 + wA * F1 + wM * (T(0.5) * F23) + wB * F4;
+        R += (x2 - x2n) + gh6 * (F1 + T(2) * F23 + F4);     // d(x2 + R) = kgut x1 dt
         x2 = x2n;
     };
+    auto no_pre = [](int) {};
+    auto no_post = [](int, T) {};
     auto glucose = [&](T y3, T y4, T y12, T cR, T cD, T X, T XL, T& d3, T& d4, T& d12) {
         p.refresh();
         const T x3 = y3 + cR;
@@ -499,9 +527,11 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
             const T v8 = cf[0] * s8 + cf[1] * s7 + cf[2] * s5 + cf[3] * s9 + cf[4] * s10 + cf[5] * s11 + cf[6] * ui;
             if (k == 0) x6m = v6; else if (k == 1) x8m = v8; else if (k == 2) x6b = v6; else x8b = v8;
         };
-        gut_step(pre, post);
+        gut_step(pre, post, s == 0);
+        if (ADAPT && refine) gut_step(no_pre, no_post, false);          // flagged lanes: the second half of this step
         const T cRm = p(DP_CF) * R, cDm = p(DP_RATC) * x2;
-        gut_step([](int) {}, [](int, T) {});
+        gut_step(no_pre, no_post, false);
+        if (ADAPT && refine) gut_step(no_pre, no_post, false);
         const T cRb = p(DP_CF) * R, cDb = p(DP_RATC) * x2;
         T k3, k4, k12, a3, a4, a12;
         glucose(z3, x4, x12, cRa, cDa, x6a, x8a, k3, k4, k12);

@@ -106,7 +106,7 @@ def test_split_tables_match_independent_matrix_exponential(n_sub):
     c6, c8 = [4, 0, 1, 2, 3, 7, 8], [6, 5, 0, 1, 2, 3, 7]
     c5, c7 = [0, 1, 2, 3, 7], [5, 0, 1, 2, 3, 7]
     for ip in range(len(names)):
-        out = np.zeros(rows + 4)
+        out = np.zeros(rows + 8)
         row = np.ascontiguousarray(tab[ip])
         assert L.t1d_split_tables(row.ctypes.data_as(dp), 45, n_sub, out.ctypes.data_as(dp), len(out)) == 0
         phi = dense[ip, :n_sub * 63].reshape(n_sub, 7, 9)
@@ -124,7 +124,7 @@ def test_split_tables_match_independent_matrix_exponential(n_sub):
         assert np.abs(phi[:, ~used]).max() < 1e-14            # what the layout drops is zero
         scale = np.maximum(np.abs(want), 1e-3)
         assert (np.abs(out[:rows] - want) / scale).max() < 1e-12, names[ip]
-        assert np.abs(out[rows:] - dense[ip, n_sub * 63:]).max() < 1e-14, names[ip]
+        assert np.abs(out[rows:] - dense[ip, n_sub * 63:]).max() < 1e-14, names[ip]      # x2 weights for h and h/2
     bad = np.zeros(10)
     assert L.t1d_split_tables(np.ascontiguousarray(tab[0]).ctypes.data_as(dp), 45, 3, bad.ctypes.data_as(dp), 10) != 0
     assert L.t1d_split_tables(np.ascontiguousarray(tab[0]).ctypes.data_as(dp), 45, 4, bad.ctypes.data_as(dp), 10) != 0

@@ -16,12 +16,12 @@ TOL_SCIPY = 1e-3
 
 
 VARIANTS = ("ref", "lds", "reg", "reg_inline", "scalar", "pipe_lds", "pipe_reg", "pipe_scalar", "split_reg", "split_lds",
-            "split_inline")
+            "split_inline", "split_adapt", "split_adapt_inline")
 
 
 def _integ(variant):
     """oracle integrator that restates what this kernel variant does"""
-    return "split" if variant.startswith("split") else "rk4"
+    return ("split_adaptive" if "adapt" in variant else "split") if variant.startswith("split") else "rk4"
 
 
 def _env(variant="scalar", **kw):
@@ -35,7 +35,8 @@ def _env(variant="scalar", **kw):
     env.set_option("scalar_params", 1 if variant in ("scalar", "pipe_scalar") else 0)
     env.set_option("pipeline", 1 if variant.startswith("pipe") else 0)
     env.set_option("params_mode", 1 if variant in ("reg", "reg_inline", "pipe_reg", "split_reg", "split_inline") else 0)
-    env.set_option("split_refill", 0 if variant in ("reg_inline", "split_inline") else 1)   # 0: noise-block refill inlined in the step kernel
+    env.set_option("adaptive_gut", 1 if "adapt" in variant else 0)
+    env.set_option("split_refill", 0 if variant in ("reg_inline", "split_inline", "split_adapt_inline") else 1)   # 0: noise-block refill inlined in the step kernel
     env.set_option("integrator", 1 if variant.startswith("split") else 0)
     return env
 
@@ -144,7 +145,8 @@ def test_config2_1024_replicas_vs_scipy(golden, variant):
     assert worst < TOL_SCIPY, worst
 
 
-@pytest.mark.parametrize("variant", ("ref", "lds", "reg", "reg_inline", "pipe_lds", "pipe_reg", "split_reg", "split_lds"))
+@pytest.mark.parametrize("variant", ("ref", "lds", "reg", "reg_inline", "pipe_lds", "pipe_reg", "split_reg", "split_lds",
+                                     "split_adapt"))
 def test_all_30_patients_24h_vs_scipy_and_oracle(golden, variant):
     """G2 for every virtual patient in one batch (heterogeneous patient ids in one wave)."""
     import torch
