@@ -7,7 +7,8 @@ BASELINE.json configs[3]'s batch -- 1 048 576 concurrent envs, patient = i mod 3
 policy (basal = U(0,2) x the patient's steady-state basal, from a pool of pre-generated action
 tensors resident in HBM), per-env random meal tables, fp64, n_sub = 4 sub-steps per minute (the library's default
 "split" fixed-step integrator: exact insulin propagator + RK4 gut/glucose, same error vs SciPy as RK4(4) on all
-13 states -- DESIGN.md section 3; `--integrator rk4` times classical RK4), Philox CGM noise.
+13 states -- DESIGN.md section 3; `--integrator rk4` times classical RK4; the gut sub-steps are halved in the
+minutes that cross a gastric-emptying transition fast unless `--fixed-step`), Philox CGM noise.
 With --gpus N each rank owns its own 1 Mi envs (weak scaling; independent episodes, no data-path
 collective); value = all ranks' env-steps / max-over-ranks wall time.
 
@@ -64,7 +65,8 @@ def main():
     ap.add_argument("--n-sub", type=int, default=4)
     ap.add_argument("--sensor", default="Navigator")
     ap.add_argument("--integrator", choices=("auto", "rk4", "split"), default="auto")
-    ap.add_argument("--adaptive-gut", action="store_true", help="split integrator with half-size gut steps across fast gastric-emptying transitions")
+    ap.add_argument("--fixed-step", action="store_true",
+                    help="switch off the split integrator's adaptive gut refinement (the library default keeps it on: DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
@@ -97,8 +99,8 @@ def main():
                            env_offset=rank * n, noise="philox", extra_outputs=False)
     env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
     integ = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else "split"
-    if a.adaptive_gut and integ == "split":
-        env.set_option("adaptive_gut", 1)
+    env.set_option("adaptive_gut", 0 if a.fixed_step else 1)
+    if integ == "split" and not a.fixed_step:
         integ = "split_adaptive"
     days = 1 + (a.steps + a.warmup) * env.minutes_per_step // 1440
     mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=0, seed=1000, device=dev, dtype=dt, env_offset=rank * n)

@@ -31,7 +31,7 @@ class BatchedT1DSimEnv:
     def __init__(self, patient="adolescent#001", n_envs=None, sensor="Dexcom", pump="Insulet",
                  dtype=torch.float64, device="cuda:0", n_sub=4, seed=0, env_offset=0, noise="philox",
                  normals=None, random_init_bg=False, extra_outputs=True, sensor_row=None, pump_row=None,
-                 patient_table=None, use_pump=True, adaptive_gut=False):
+                 patient_table=None, use_pump=True, adaptive_gut=True):
         self._L = _lib.lib()                     # raises T1DError if the HIP extension is missing
         if not torch.cuda.is_available():
             raise _lib.T1DError("BatchedT1DSimEnv needs a ROCm GPU (torch.cuda.is_available() is False)")
@@ -80,8 +80,8 @@ class BatchedT1DSimEnv:
         _lib.check(self._L.t1d_ctx_create(dev_index, tab.ctypes.data_as(dp), tab.shape[0], tab.shape[1],
                                           self.sensor_row.ctypes.data_as(dp), self.pump_row.ctypes.data_as(dp),
                                           C.byref(self._ctx)))
-        if adaptive_gut:       # split integrator: half-size gut steps in the minutes that cross a gastric-emptying transition fast
-            self.set_option("adaptive_gut", 1)
+        # split integrator: half-size gut steps in the minutes that cross a gastric-emptying transition fast (library default)
+        self.set_option("adaptive_gut", 1 if adaptive_gut else 0)
         n, dv, ft = self.n, self.device, dtype
         z = lambda *shape, dt=ft: torch.zeros(*shape, dtype=dt, device=dv)
         # packed state (include/t1d.h): one [44, n] float buffer and one [4, n] int32 buffer; the named

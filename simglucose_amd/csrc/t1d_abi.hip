@@ -1175,7 +1175,7 @@ struct t1d_ctx {
     int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
     int split_refill = 1;    // 1 = noise-block refills run in their own kernel ahead of a refill-free step kernel
     int pipe_stagger = 0;    // s_sleep(127) iterations (~3.4 us each) by which the second half of the persistent grid starts late
-    int adaptive_gut = 0;    // 1 = the split integrator halves the gut step in minutes that cross a gastric-emptying transition fast
+    int adaptive_gut = 1;    // 1 (default) = the split integrator halves the gut step in minutes that cross a gastric-emptying transition fast
     int single_minute_kernel = 1;   // 1 = minutes == 1 launches of the split integrator use the persistent early-store kernel
     int integrator = -1;     // 0 = classical RK4 on all 13 states, 1 = split scheme, -1 = split whenever n_sub allows it
     int split_nsub = 0;      // n_sub the split tables on the device were built for (0 = none yet)

@@ -53,7 +53,7 @@ def test_meal_table_equals_dense_cho_and_oracle(sensor):
             e.set_meals(mt, ma)
         e.reset()
         envs.append(e)
-    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="split", n_sub=4)     # the default integrator at even n_sub
+    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="split_adaptive", n_sub=4)     # the default integrator at even n_sub
     orc.reset()
     b = _basal(pid)
     for k in range(nstep):
@@ -83,7 +83,7 @@ def test_philox_noise_replays_through_host_normals_and_oracle():
     assert stats.kstest(zz[:, ::7].ravel(), "norm").pvalue > 1e-4
     assert abs(np.corrcoef(zz[0], zz[1])[0, 1]) < 0.06
     e2 = _mk(patient=pid, sensor="Dexcom", noise="host", normals=z, n_sub=2)
-    orc = O.OracleEnv(pid, sensor="Dexcom", normals=zz, integrator="split", n_sub=2)
+    orc = O.OracleEnv(pid, sensor="Dexcom", normals=zz, integrator="split_adaptive", n_sub=2)
     o1, o2, r = e1.reset().clone(), e2.reset().clone(), orc.reset()
     assert torch.equal(o1, o2)
     assert np.abs(o1.cpu().numpy() - r["cgm"]).max() < 1e-9
@@ -244,7 +244,7 @@ def test_rollout_bb_config1_matches_reference_host_loop_and_oracle(golden):
     # (c) the oracle's closed loop with the same scheme, every patient of the batch
     for j, nm in enumerate(names):
         hist, a = O.closed_loop(nm, "Dexcom", 1, 1, K, lambda cgm, info, nm=nm: O.bb_policy(nm, info["meal"], cgm, info["sample_time"]),
-                                integrator="split", n_sub=4)
+                                integrator="split_adaptive", n_sub=4)
         assert np.abs(bg_a[:, 16 * j] - hist["BG"][1:]).max() < 1e-8, nm
         assert np.abs(cgm_a[:, 16 * j] - hist["CGM"][1:]).max() < 1e-8, nm
     assert ea.sync() == 0 and eb.sync() == 0
@@ -267,11 +267,11 @@ def test_split_integrator_other_substep_counts_and_table_rebuild(n_sub):
     b = _basal(pid)
     cho = np.zeros((60, n)); cho[5] = 60.0; cho[20, ::2] = 25.0
     e.step(torch.as_tensor(b, device=e.device), cho=cho[0:1])                 # builds the n_sub = 4 tables first
-    orc4 = O.OracleEnv(pid, sensor="Navigator", normals=z, integrator="split", n_sub=4)
+    orc4 = O.OracleEnv(pid, sensor="Navigator", normals=z, integrator="split_adaptive", n_sub=4)
     orc4.reset(); r = orc4.step(b, None, cho[0:1])
     assert np.abs(e.bg.cpu().numpy() - r["bg"]).max() < 1e-8
     e.n_sub = n_sub                                                            # forces a rebuild of the tables
-    orc = O.OracleEnv(pid, sensor="Navigator", normals=z, integrator="split", n_sub=n_sub)
+    orc = O.OracleEnv(pid, sensor="Navigator", normals=z, integrator="split_adaptive", n_sub=n_sub)
     orc.reset()
     for k in ("x", "planned", "last_qsto", "last_food", "last_cgm", "ar_e", "pts", "prev_cgm"):
         getattr(orc, k)[...] = getattr(orc4, k)
@@ -362,7 +362,7 @@ def test_custom_patient_table_with_more_than_32_patients(sensor):
     pid = np.arange(n) % 44
     z = rs.randn(20, n)
     e = _mk(patient=pid, patient_table=big, sensor=sensor, noise="host", normals=z, n_sub=4)
-    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="split", n_sub=4, ptab_override=big)
+    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="split_adaptive", n_sub=4, ptab_override=big)
     o0, r0 = e.reset(), orc.reset()
     assert np.abs(o0.cpu().numpy() - r0["cgm"]).max() < 1e-9
     st = int(e.minutes_per_step)

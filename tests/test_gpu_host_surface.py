@@ -126,7 +126,7 @@ def test_standalone_patient_steps():
         cho = 50.0 if t == 10 else 0.0
         ins = basal * (3.0 if 10 <= t < 13 else 1.0)
         p.step(Action(CHO=cho, insulin=ins))
-        orc.step(cho, ins, integrator="split", n_sub=4)
+        orc.step(cho, ins, integrator="split_adaptive", n_sub=4)
     assert p.t == 90
     assert np.abs(p.state - orc.x).max() < 1e-7
     p.reset()

@@ -92,7 +92,7 @@ def test_env_step_dopri_matches_reference(golden, sensor, seed, pname):
     nstep = len(g["basal_" + tag])
     cho = O.custom_scenario_cho(g["scen_hours"], g["scen_grams"], nstep * st)
     worst = {}
-    for integ, tol in (("dopri", 1e-8), ("rk4", 1e-3), ("split", 1e-3)):
+    for integ, tol in (("dopri", 1e-8), ("rk4", 1e-3), ("split", 1e-3), ("split_adaptive", 1e-3)):
         env = O.OracleEnv([names.index(pname)], sensor=sensor, normals=g["randn_" + tag][:, None], integrator=integ, n_sub=4)
         r0 = env.reset()
         assert abs(r0["cgm"][0] - float(g["reset_cgm_" + tag])) < 1e-12
@@ -124,7 +124,7 @@ def test_open_loop_24h_all_patients(golden):
     names, tab = O.patient_table()
     meal = dict(zip(g["meal_minute"].tolist(), g["meal_grams"].tolist()))
     mult = g["action_mult"]
-    for integ, tol in (("dopri", 2e-5), ("rk4", 1e-3), ("split", 1e-3)):
+    for integ, tol in (("dopri", 2e-5), ("rk4", 1e-3), ("split", 1e-3), ("split_adaptive", 1e-3)):
         worst = 0.0
         for ip in range(30):
             p = O.PatientOracle(tab[ip])
@@ -160,7 +160,7 @@ def test_upstream_golden_file_closed_loop():
     assert np.abs(hist["CHO"] - ref["CHO"][:-1]).max() < 1e-12
     assert np.abs(hist["insulin"] - ref["insulin"][:-1]).max() < 1e-9
     # and through RK4(4): BASELINE's bar on the glucose columns
-    for integ in ("rk4", "split"):
+    for integ in ("rk4", "split", "split_adaptive"):
         hist4, _ = O.closed_loop("adolescent#001", "Dexcom", 1, 1, 960, _bb("adolescent#001"), integrator=integ, n_sub=4)
         assert np.abs(hist4["BG"] - ref["BG"]).max() < 1e-3, integ
         assert np.abs(hist4["CGM"] - ref["CGM"]).max() < 1e-3, integ
@@ -216,3 +216,37 @@ def test_report_statistics_restatement(golden):
     assert sorted(set(zone.tolist())) == [0, 1, 2, 3, 4, 5]          # the fixture exercises every zone
     L, H = O.report_risk_index_trace(g["bg"])                        # parity unpinned (see its docstring): sanity only
     assert L.shape == (25, 30) and np.all((L == 0) | (H == 0))
+
+
+def test_adaptive_split_on_random_scenario_days():
+    """Beyond the fixtures: 60 env-days of RandomScenario draws with a new random basal rate every minute (the class
+    of workload bench.py times).  Against the SciPy-faithful DOPRI5 path and against a tight solve (RK4, 64
+    sub-steps): the fixed-step split scheme leaves the 1e-3 band on some days, the adaptive one only where SciPy's
+    own default tolerance does (tools/random_scenario_error.py runs 300 days)."""
+    names, tab = O.patient_table()
+    rs = np.random.RandomState(5)
+    n, K = 60, 1440
+    pid = (np.arange(n) * 7) % 30
+    cho = np.zeros((K, n))
+    for j in range(n):
+        t, a = O.random_scenario_draw(rs)
+        for tt, aa in zip(t, a):
+            if tt < K:
+                cho[int(tt), j] = aa
+    basal0 = tab[pid, O.IDX["u2ss"]] * tab[pid, O.IDX["BW"]] / 6000.0
+    pool = [basal0 * 2 * rs.rand(n) for _ in range(8)]
+    z = np.zeros((120, n))
+
+    def run(integ, ns):
+        e = O.OracleEnv(pid, sensor="Navigator", normals=z, integrator=integ, n_sub=ns)
+        e.reset()
+        out = np.empty((K, n))
+        for k in range(K):
+            out[k] = e.step(pool[k % 8], None, cho[k:k + 1])["bg"]
+        return out
+    ref, tight = run("dopri", 4), run("rk4", 64)
+    fixed, adapt = run("split", 4), run("split_adaptive", 4)
+    w = lambda o, r: np.abs(o - r).max(0)
+    assert w(adapt, tight).max() < 1e-3                                   # within 1e-3 of the tight solve on every day
+    assert (w(adapt, ref) <= 1e-3).mean() >= 0.95 and w(adapt, ref).max() <= w(ref, tight).max() + 1e-3
+    assert w(adapt, tight).max() < 0.5 * w(fixed, tight).max()            # and a real gain over the fixed steps
