@@ -445,7 +445,6 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
     // in post(), so that their latency hides behind ~50 dependent VALU instructions instead of being waited out.
     // per-lane gut step and x2 weights (ADAPT: halved in flagged minutes; the flag is known after the first stage
     // of the minute, whose value F1 = kgut x1 at the start does not depend on the step)
-    T gh = h, ghh = hh, gh6 = h6;
     bool refine = false;
     auto gut_step = [&](auto&& pre, auto&& post, bool first_of_minute) {
         p.refresh();
@@ -462,8 +461,9 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
             const bool fa = fabs(dA) > T(4) && (A0 * A1 <= T(0) || t_min(fabs(A0), fabs(A1)) < T(3));
             const bool fc = fabs(dC) > T(4) && (C0 * C1 <= T(0) || t_min(fabs(C0), fabs(C1)) < T(3));
             refine = fa || fc;
-            gh = refine ? T(0.5) * h : h; ghh = T(0.5) * gh; gh6 = gh / T(6);
         }
+        const T sc = (ADAPT && refine) ? T(0.5) : T(1);                 // exact scalings: the step sizes are not kept in registers
+        const T gh = sc * h, ghh = sc * hh, gh6 = sc * h6;
         const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;
         T y0 = g0 + ghh * a0, y1 = g1 + ghh * a1;
         pre(1);
