@@ -68,17 +68,35 @@ class Outcome(C.Structure):
                 ("q_lo", C.c_double), ("q_hi", C.c_double), ("chunk", C.c_int32)]
 
 
+def _stale():
+    return not os.path.exists(LIB_PATH) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH)
+                                               for s in SOURCES)
+
+
 def build(force=False, verbose=False):
-    """Compile libt1d_hip.so for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
-    stale = force or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in SOURCES)
-    if stale:
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-o", LIB_PATH, SOURCES[0]]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.check_call(cmd)
+    """Compile libt1d_hip.so for gfx950 in-tree with hipcc (cross-compiles without a GPU).  Safe when several
+    processes (one per GPU) find the library stale at once: one builds under a file lock into a temporary
+    file that is moved into place, the others wait and then find it fresh."""
+    import fcntl
+    if not (force or _stale()):
+        return LIB_PATH
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _stale():
+                hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+                tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp, SOURCES[0]]
+                if verbose:
+                    cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                try:
+                    subprocess.check_call(cmd)
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -92,8 +110,7 @@ def lib():
     if _lib is not None:
         return _lib
     try:
-        if not os.path.exists(LIB_PATH) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH)
-                                               for s in SOURCES):
+        if _stale():
             build()
         L = C.CDLL(LIB_PATH)
     except (OSError, subprocess.CalledProcessError, FileNotFoundError) as e:
