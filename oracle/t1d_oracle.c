@@ -209,8 +209,12 @@ static void o_glucose_rhs(const double* p, const double* y, double cR, double cR
     dy[0] = d3; dy[1] = d4; dy[2] = d12;
 }
 
+#ifndef T1D_O_ADAPT_NEAR
 #define T1D_O_ADAPT_NEAR 3.0     /* |tanh argument| below this somewhere in the minute ... */
+#endif
+#ifndef T1D_O_ADAPT_MOVE
 #define T1D_O_ADAPT_MOVE 4.0     /* ... while it changes by more than this over the minute */
+#endif
 int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
                        double lf, int ng, int adapt)
 {
