@@ -1623,7 +1623,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
         if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_step: split tables exceed 64 KiB of LDS (n_patients x n_sub too large); use integrator 0");
     }
-    const int variant = c->math == 0 ? 0 : (split ? (c->adaptive_gut ? 7 : (pmode ? 4 : 5)) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
+    const int variant = c->math == 0 ? 0 : (split ? (c->adaptive_gut ? ((pmode && b->dtype == T1D_F32) ? 6 : 7) : (pmode ? 4 : 5)) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
     // (the adaptive scheme always takes its parameters from LDS: with them in VGPRs as well it spills)
 #define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
 #define T1D_LAUNCH_PIPE(V, TT) hipLaunchKernelGGL((step_pipe_kernel<V, TT>), pgrid, dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
@@ -1691,9 +1691,11 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
                                                       default: T1D_LAUNCH_FAST(7, double); break; } }
         else { switch (variant) { case 1: T1D_LAUNCH_FAST(1, float); break; case 2: T1D_LAUNCH_FAST(2, float); break; case 3: T1D_LAUNCH_FAST(3, float); break;
                                   case 4: T1D_LAUNCH_FAST(4, float); break; case 5: T1D_LAUNCH_FAST(5, float); break;
-                                  default: T1D_LAUNCH_FAST(7, float); break; } }
+                                  case 6: T1D_LAUNCH_FAST(6, float); break; default: T1D_LAUNCH_FAST(7, float); break; } }
     } else if (b->dtype == T1D_F64) {
         T1D_BY_VARIANT(T1D_LAUNCH_STEP, double);
+    } else if (variant == 6) {           // fp32 only: with the parameters in VGPRs the adaptive scheme fits there (fp64 spills)
+        T1D_LAUNCH_STEP(6, float);
     } else {
         T1D_BY_VARIANT(T1D_LAUNCH_STEP, float);
     }
