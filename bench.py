@@ -88,8 +88,23 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # T1D_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL init, barriers, max-reduce) with a single rank too:
+    # a one-GPU box can rehearse what the N > 1 launches do
+    use_dist = world > 1 or (os.environ.get("T1D_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        # RCCL prints its version banner on stdout while the communicator comes up: send that to stderr, so that
+        # stdout carries nothing but the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     n = a.envs
     dt = torch.float64 if a.dtype == "f64" else torch.float32
@@ -116,7 +131,7 @@ def main():
     EV_STRIDE = 8
     ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, a.steps, EV_STRIDE)}
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -128,12 +143,12 @@ def main():
         if e is not None:
             e[1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     status = env.sync(raise_on_status=False)
-    if world > 1:
+    if use_dist:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
@@ -175,7 +190,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_envs, a.cpu_steps, a.n_sub, a.sensor, integ)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
