@@ -7,7 +7,8 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("T1D_LIB_PATH") or os.path.join(_PKG, "libt1d_hip.so")   # override: A/B builds only
-SOURCES = [os.path.join(_PKG, "csrc", "t1d_abi.hip"), os.path.join(_PKG, "csrc", "t1d_device.hpp"),
+SOURCES = [os.path.join(_PKG, "csrc", "t1d_abi.hip"), os.path.join(_PKG, "csrc", "t1d_kernels.hpp"),
+           os.path.join(_PKG, "csrc", "t1d_device.hpp"),
            os.path.join(_ROOT, "include", "t1d.h")]
 
 T1D_F64, T1D_F32 = 0, 1

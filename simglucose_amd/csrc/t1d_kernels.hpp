@@ -1,0 +1,1151 @@
+// t1d_kernels.hpp -- the HIP kernels of libt1d_hip.so (gfx950 only).  Included by t1d_abi.hip, which holds the host
+// side of the C ABI (include/t1d.h); the per-lane arithmetic (RHS, integrators, sensor, risk) is in t1d_device.hpp.
+//
+//   step1_kernel       the headline launch: ONE simulated minute per env.step, split integrator, one persistent
+//                      workgroup per CU whose waves draw 64-env chunks from a queue in LDS.
+//   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
+//                      n_sub sub-steps -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
+//   refill_kernel      rebuilds due 150-minute CGM noise blocks ahead of a step kernel compiled without that code.
+//   step_pipe_kernel   step_kernel made persistent with LDS-DMA prefetch (classical RK4; experiment, off by default).
+//   rollout_pid_kernel n_steps x (PID or basal-bolus policy + step) with state in registers.
+//   reset_kernel       masked T1DSimEnv.reset().                                              (env.py:119-155)
+//   random_meals_kernel  RandomScenario.create_scenario for the whole batch.          (scenario_gen.py:33-60)
+//   outcome_kernel     time in range, CVGA percentiles and risk means of a BG history.   (analysis/report.py:74-217)
+//   philox_normals_kernel  replays the Philox stream for tests.
+#pragma once
+#include "../../include/t1d.h"
+#include "t1d_device.hpp"
+
+#ifndef T1D_WAVES
+#define T1D_WAVES 2
+#endif
+#ifndef T1D_ROW_RECOMPUTE
+#define T1D_ROW_RECOMPUTE 1
+#endif
+
+#include <climits>
+#include <cstdint>
+
+namespace t1d {
+
+template <typename T> struct KArgs {
+    int64_t n, env_offset;
+    uint64_t seed;
+    T* x; T* planned; T* last_qsto; T* last_food; int32_t* t; uint32_t* meta; uint32_t* episode; int32_t* next_meal;
+    T* last_cgm; T* ar_e; T* pts; T* prev_cgm;
+    const T* basal; const T* bolus; const T* cho; const int32_t* meal_time; const T* meal_amt;
+    const T* normals; const T* x0_override;
+    T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin;
+    const T* dpar;          // [DP_COUNT][kMaxPatients] derived patient constants
+    const T* prop;          // [prop_rows][np_pad] insulin propagator of the split integrator (kPropRows(n_sub) rows)
+    const double* x0tab;    // [13][np]
+    const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
+    int* status;
+    long long* trace;       // T1D_S1_TRACE builds only: phase timestamps of the first blocks' waves
+    SensorC<T> sen; PumpC<T> pump;
+    int np, S, n_meals, n_normals, minutes, n_sub, flags, stagger, prop_rows, np_pad;
+};
+
+template <typename T> struct PidArgs {
+    T P, I, D, target;
+    T* integ; T* prev; T* sum_risk; T* min_bg; T* max_bg; int32_t* n_low; int32_t* n_high;
+    int n_steps;
+    int kind;               // 0 = PIDController, 1 = BBController
+    const T* bb_basal; const T* bb_cr; const T* bb_cf; T* bb_prev_meal;
+    T* bg_trace; T* cgm_trace; T* cho_trace; T* ins_trace; int64_t trace_row;
+};
+
+// Row k of a [K][n] array as a wave-uniform base pointer: the lane index i then rides in ONE 32-bit
+// VGPR offset shared by every array (global_load ... v_off, s[base]) instead of a 64-bit address
+// pair per array kept alive from the first load to the last store.
+// The empty asm pins the row base in an SGPR pair and hides its provenance, so loads and stores take the
+// `global_* v_off, s[base:base+1]` form and no per-row 64-bit VGPR address survives from load to store.
+template <typename U> __device__ __forceinline__ U* row(U* base, int64_t n, int k)
+{
+#if T1D_ROW_RECOMPUTE
+    // the (volatile) asm keeps the row offset in scalar registers AND stops the compiler from hoisting dozens of
+    // loop-invariant row pointers out of a tile loop, where they would overflow the SGPR file and be parked in
+    // VGPR lanes (v_writelane / v_readlane around every access): a few scalar ops per access are cheaper
+    int kk = k;
+    asm volatile("" : "+s"(kk));
+    return base + (int64_t)kk * n;
+#else
+    U* p = base + (int64_t)k * n;
+    asm volatile("" : "+s"(p));
+    return p;
+#endif
+}
+// row whose index may differ between lanes (meal cursor, noise block): ordinary per-lane address
+template <typename U> __device__ __forceinline__ U* rowv(U* base, int64_t n, int k) { return base + (int64_t)k * n; }
+// element i of a uniform-base array through an explicit 32-bit BYTE offset (i < 2^28 by contract)
+// The access goes through an explicit address_space(1) pointer: row() hides a pointer's provenance, and a
+// pointer the compiler cannot trace back to a kernel argument is accessed with FLAT instructions, which
+// count on BOTH vmcnt and lgkmcnt -- every LDS wait of the integration loop would then also wait for them.
+template <typename U> struct GRef {
+    __attribute__((address_space(1))) U* p;
+    __device__ __forceinline__ operator U() const { return *p; }
+    __device__ __forceinline__ const GRef& operator=(U v) const { *p = v; return *this; }
+};
+template <typename U> __device__ __forceinline__ GRef<U> at(U* base, unsigned i)
+{
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) U gU;
+    return GRef<U>{(gU*)((gchar*)base + (unsigned)(i * (unsigned)sizeof(U)))};
+}
+
+// env state held in registers across the minutes of a launch
+template <typename T> struct Env {
+    T x[13];
+    T planned, lq, lf, last_cgm, prev_cgm;
+    T cur[4];           // current 15-min interval of the noise spline (pts rows 22..25)
+    int t, cursor, next_meal, next_meal_loaded;
+    bool eating;
+};
+template <typename T> struct StepOut { T cgm, bg, meal, ins; };
+
+template <typename T>
+__device__ __forceinline__ void stage_pars(const KArgs<T>& a, T* lds, int rows = DP_COUNT)
+{
+    const int tot = rows * kMaxPatients;
+    for (int j = threadIdx.x; j < tot; j += blockDim.x) lds[j] = a.dpar[j];
+    __syncthreads();
+}
+
+// the split integrator's propagator table into (dynamic) LDS; same [rows][np_pad] layout as in memory
+template <typename T>
+__device__ __forceinline__ void stage_prop(const KArgs<T>& a, T* lds)
+{
+    const int tot = a.prop_rows * a.np_pad;
+    for (int j = threadIdx.x; j < tot; j += blockDim.x) lds[j] = a.prop[j];
+    __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void load_env(const KArgs<T>& a, unsigned i, uint32_t meta, Env<T>& e)
+{
+#pragma unroll
+    for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
+    e.planned = at(a.planned, i); e.lq = at(a.last_qsto, i); e.lf = at(a.last_food, i);
+    e.last_cgm = at(a.last_cgm, i); e.prev_cgm = at(a.prev_cgm, i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.pts, a.n, 22 + k), i);
+    e.t = at(a.t, i);
+    e.next_meal = a.next_meal ? at(a.next_meal, i) : 0;
+    e.next_meal_loaded = e.next_meal;
+    e.eating = (meta & T1D_META_EATING) != 0;
+    e.cursor = (int)T1D_META_CURSOR(meta);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_t pid, const Env<T>& e)
+{
+#pragma unroll
+    for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
+    at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
+    at(a.last_cgm, i) = e.last_cgm; at(a.prev_cgm, i) = e.prev_cgm;
+    at(a.t, i) = e.t;
+    if (a.next_meal && e.next_meal != e.next_meal_loaded) at(a.next_meal, i) = e.next_meal;
+    at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+}
+
+// Refill of the CGM noise deque (noise_gen.py:30-56): ten new AR(1) -> Johnson-SU points at 15-min
+// spacing (:84-97) behind the carried-over last point.  Runs once per 150 simulated minutes per env,
+// so it is kept out of line: its registers (ocml sinh, Philox) are paid for on this path only.
+// Returns sample 0 of the new block, W[0] . points.
+// ---- CGM noise (sensor/noise_gen.py) ----------------------------------------------------------------
+// The reference interpolates each block of 11 Johnson-SU points (15-min spacing, 150 min) with
+// scipy's interp1d(kind='cubic') = the not-a-knot cubic spline, and hands out its values on the sensor
+// grid (noise_gen.py:38-47).  That spline is evaluated here in its local form instead of as a dense
+// 11-tap operator per sample: with M = second derivatives at the knots (M = Minv . y, Minv fixed),
+//   S(tau) = A y_m + B y_{m+1} + ((A^3 - A) M_m + (B^3 - B) M_{m+1}) h^2/6,  A = (t_{m+1} - tau)/h, B = 1 - A,
+// so a sample reads 4 words (rows 22..25 of `pts`, the current interval) instead of 11 + 11, and the
+// rows it reads do not depend on the env's clock (they can be fetched with the rest of the state).
+// pts rows: 0..10 = y (points of the block), 11..21 = M, 22..25 = (y_m, y_{m+1}, M_m, M_{m+1}).
+constexpr int kPtsRows = 26;
+
+#ifndef T1D_REFILL_INLINE
+#define T1D_REFILL_INLINE 1
+#endif
+#if T1D_REFILL_INLINE
+#define T1D_REFILL_ATTR __forceinline__
+#else
+#define T1D_REFILL_ATTR __noinline__
+#endif
+
+// Refill of the CGM noise deque (noise_gen.py:30-56): ten new AR(1) -> Johnson-SU points behind the
+// carried-over last point (:84-97), then the knot second derivatives.  Once per 150 simulated minutes.
+template <typename T>
+__device__ T1D_REFILL_ATTR void noise_refill(T* __restrict__ pts, const T* __restrict__ normals, const T* __restrict__ minv,
+                                             const uint32_t* __restrict__ episode, int* status, int64_t n, unsigned i,
+                                             int64_t env_offset, uint64_t seed, int n_normals, int b, SensorC<T> sen, T* ar_e)
+{
+    const T p0 = at(rowv(pts, n, b > 0 ? 10 : 0), i);    // carried-over last point (:33,36)
+    at(pts, i) = p0;
+    T M[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) M[k] = minv[k * 11] * p0;
+    T e = *ar_e;
+    const uint32_t ep = (!normals && episode) ? at(episode, i) : 0u;
+#pragma unroll 1
+    for (int q = 0; q < 5; ++q) {
+        T z0, z1;
+        if (normals) {
+            const int d = 1 + 10 * b + 2 * q;
+            if (d + 1 < n_normals) { z0 = at(rowv(normals, n, d), i); z1 = at(rowv(normals, n, d + 1), i); }
+            else { z0 = z1 = T(0); atomicOr(status, T1D_ST_NORMALS_EXHAUSTED); }
+        } else {
+            const double2 r = philox_pair(seed, (uint64_t)(env_offset + i), ep, 3u + 5u * (uint32_t)b + (uint32_t)q);
+            z0 = (T)r.x; z1 = (T)r.y;
+        }
+        e = sen.pacf * (e + z0);                         // :88
+        const T ya = johnson_su<true>(sen, e);
+        e = sen.pacf * (e + z1);
+        const T yb = johnson_su<true>(sen, e);
+        at(rowv(pts, n, 2 * q + 1), i) = ya;
+        at(rowv(pts, n, 2 * q + 2), i) = yb;
+        const T* mc = minv + (2 * q + 1);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) M[k] += mc[k * 11] * ya + mc[k * 11 + 1] * yb;
+    }
+    *ar_e = e;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) at(rowv(pts, n, 11 + k), i) = M[k];
+}
+
+// next(CGMNoise) for sample index s (noise_gen.py:61-69).  cur = rows 22..25 of pts as loaded with the
+// env state; updated (and stored) when the sample enters a new 15-minute interval.
+// REFILL = false: the block has already been rebuilt by refill_kernel (t1d_step launches it ahead of the
+// step kernel), which keeps the rarely-run refill code -- Philox, Box-Muller, ten Johnson transforms, the
+// 11x11 spline operator -- and above all its registers out of the step kernel: with it inlined the fp64
+// step kernel needs 256 VGPRs + scratch, without it 180-220 and no scratch (117 vs 140 us at 1 Mi envs).
+// x / d and x % d for x >= 0 and a wave-uniform d.  An integer division by a run-time divisor costs ~20 VALU
+// instructions, three of them quarter-rate; the sensor grid only ever divides by sample_time (1, 3, 5 minutes
+// for the reference's sensors) and by samples-per-block 150 / sample_time, so those take a uniform branch to a
+// compile-time divisor (a multiply-high and a shift) and anything else the general path.
+__device__ __forceinline__ void divmod_uniform(int x, int d, int& q, int& r)
+{
+    switch (d) {
+        case 1: q = x; r = 0; return;
+        case 3: q = x / 3; break;
+        case 5: q = x / 5; break;
+        case 30: q = x / 30; break;
+        case 50: q = x / 50; break;
+        case 150: q = x / 150; break;
+        default: q = x / d; break;
+    }
+    r = x - q * d;
+}
+
+template <bool REFILL, typename T>
+__device__ __forceinline__ T noise_sample(const KArgs<T>& a, unsigned i, int s, T (&cur)[4])
+{
+    const int64_t n = a.n;
+    const int st = a.sen.st;
+    int j, b;
+    divmod_uniform(s, a.S, b, j);
+    const int tau = (j + 1) * st;
+    const int m = tau / 15 < 9 ? tau / 15 : 9;
+    const int mprev = (tau - st) / 15 < 9 ? (tau - st) / 15 : 9;
+    if (REFILL && j == 0) {             // deque empty: build the next 150-minute block
+        T e = at(a.ar_e, i);            // the AR(1) state is touched by refills only
+        noise_refill<T>(a.pts, a.normals, a.minv, a.episode, a.status, n, i, a.env_offset, a.seed, a.n_normals, b, a.sen, &e);
+        at(a.ar_e, i) = e;
+    }
+    if (j == 0 || m != mprev) {         // entering interval m: fetch its knots (every 15 minutes)
+        cur[0] = at(rowv(a.pts, n, m), i);      cur[1] = at(rowv(a.pts, n, m + 1), i);
+        cur[2] = at(rowv(a.pts, n, 11 + m), i); cur[3] = at(rowv(a.pts, n, 12 + m), i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) at(row(a.pts, n, 22 + k), i) = cur[k];
+    }
+    const T B = T(tau - 15 * m) * T(1.0 / 15.0), A = T(1) - B;
+    return A * cur[0] + B * cur[1] + T(37.5) * ((A * A * A - A) * cur[2] + (B * B * B - B) * cur[3]);
+}
+
+// CGMSensor.measure (cgm.py:26-36) split in two so that the memory latency of the noise block hides
+// under the ODE integration: the noise of the sample due at minute t+1 does not depend on the
+// patient state, so it is drawn BEFORE the RK4 sub-steps (sample index = 1 + (t+1)/st: reset used
+// #0 and #1) and added to Gsub after them.
+template <bool REFILL, typename T>
+__device__ __forceinline__ T measure_noise(const KArgs<T>& a, unsigned i, Env<T>& e, bool& due)
+{
+    const int t1 = e.t + 1;
+    int q, r;
+    divmod_uniform(t1, a.sen.st, q, r);
+    due = r == 0;
+    return due ? noise_sample<REFILL>(a, i, 1 + q, e.cur) : T(0);
+}
+template <typename T>
+__device__ __forceinline__ T measure_apply(const KArgs<T>& a, Env<T>& e, T gsub, T noise, bool due)
+{
+    if (due) {
+        T cgm = gsub + noise;
+        cgm = cgm > a.sen.vmin ? cgm : a.sen.vmin;
+        cgm = cgm < a.sen.vmax ? cgm : a.sen.vmax;
+        e.last_cgm = cgm;
+    }
+    return e.last_cgm;
+}
+
+// scenario.get_action(time) from the per-env meal table (scenario.py:33-42 / scenario_gen.py:23-31).
+// With the `next_meal` state array the common minute costs no table access at all: the minute of the
+// next entry travels with the env state and the table is touched only when a meal fires.
+template <typename T>
+__device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& e)
+{
+    T meal = T(0);
+    if (a.next_meal) {
+        if (e.next_meal <= e.t) {                       // rare: a meal fires (or stale entries are skipped)
+            while (e.cursor < a.n_meals) {
+                const int mt = at(rowv(a.meal_time, a.n, e.cursor), i);
+                if (mt > e.t) { e.next_meal = mt; break; }
+                if (mt == e.t) meal = at(rowv(a.meal_amt, a.n, e.cursor), i);
+                ++e.cursor;
+            }
+            if (e.cursor >= a.n_meals) e.next_meal = INT_MAX;
+        }
+    } else if (e.cursor < a.n_meals) {
+        int mt = at(rowv(a.meal_time, a.n, e.cursor), i);
+        while (mt < e.t && ++e.cursor < a.n_meals) mt = at(rowv(a.meal_time, a.n, e.cursor), i);
+        if (e.cursor < a.n_meals && mt == e.t) {
+            meal = at(rowv(a.meal_amt, a.n, e.cursor), i);
+            ++e.cursor;
+        }
+    }
+    return meal;
+}
+
+// T1DSimEnv.step body (env.py:66-84): `minutes` mini_steps with one action.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `pre_rk4` runs once, immediately before the first minute's RK4 sub-steps: from there to the end of
+// the integration the wave issues no vector-memory instruction, which is where the persistent kernel
+// starts the LDS-DMA of its next tile.
+template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false, bool REFILL = true, typename PR = NoProp>
+__device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
+                                                T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook(), PR pr = PR())
+{
+    T q_basal, q_bolus;
+    if (a.flags & (T1D_BATCH_NO_PUMP | 0x200)) { // T1DPatient.step driven directly: insulin = basal + bolus as given
+        q_basal = basal; q_bolus = has_bolus ? bolus : T(0);
+    } else {
+        q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
+        q_bolus = a.pump.min_bolus > T(0) ? a.pump.min_bolus : T(0);     // = pump.bolus(0)
+        if (has_bolus) q_bolus = pump_quantise(bolus, a.pump.inc_bolus, a.pump.min_bolus, a.pump.max_bolus);   // env.py:52
+    }
+    const T insulin = q_basal + q_bolus;
+    const T div = T(a.minutes), inv_div = T(1) / div;
+    StepOut<T> o{T(0), T(0), T(0), T(0)};
+    for (int m = 0; m < a.minutes; ++m) {
+        const T meal = a.cho ? at(row(a.cho, a.n, m), i) : meal_lookup(a, i, e);      // env.py:50
+        bool due;
+        const T noise = (a.flags & 0x400) ? (due = false, T(0)) : measure_noise<REFILL>(a, i, e, due);
+        MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+        // every load this minute issued is needed by the integration anyway: drain them HERE, on every
+        // path, so that the compiler's own wait cannot land behind the hook's (invisible) DMA instructions
+        if constexpr (PR::kSplit) p.pin_split(); else p.pin();
+        {   // volatile asms keep their order: everything the RK4 loop consumes is computed (and any spilled
+            // operand reloaded) BEFORE the hook below issues its DMA
+            T aa = u.aa, cc = u.cc, bD = u.bD, dD = u.dD, dmg = u.d_mg, ins = u.ins;
+            asm volatile("" : "+v"(aa), "+v"(cc), "+v"(bD), "+v"(dD), "+v"(dmg), "+v"(ins));
+            u.aa = aa; u.cc = cc; u.bD = bD; u.dD = dD; u.d_mg = dmg; u.ins = ins;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+        if (m == 0) pre_rk4();
+        if constexpr (PR::kSplit) { if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub); }
+        else { if (!(a.flags & 0x800)) rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP); }
+        e.t += 1;
+        const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
+        const T cgm = measure_apply(a, e, gsub, noise, due);                      // env.py:62
+        if (MATH == 0) { o.meal += meal / div; o.ins += insulin / div; o.bg += gsub / div; o.cgm += cgm / div; }   // env.py:78-81
+        else { o.meal += meal * inv_div; o.ins += insulin * inv_div; o.bg += gsub * inv_div; o.cgm += cgm * inv_div; }
+    }
+    if (MATH != 0 && a.minutes == 1) { o.ins = insulin; }   // x * (1/1) is exact already; keeps -0 out
+    return o;
+}
+
+// risk of CGM_hist[-1] (risk_diff, env.py:27-33): independent of this step's integration, so callers
+// evaluate it BEFORE the minute loop, where it overlaps with the pump / meal / noise chains
+template <int MATH, typename T>
+__device__ __forceinline__ T prev_risk(const KArgs<T>& a, T prev_cgm)
+{
+    T l, h, rp = T(0);
+    if (!(a.flags & 0x100)) risk_index1<MATH>(prev_cgm, l, h, rp);
+    return rp;
+}
+
+template <int MATH, typename T>
+__device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env<T>& e, const StepOut<T>& o, T rp)
+{
+    T l, h, r, rc = T(0);
+    if (!(a.flags & 0x100)) risk_index1<MATH>(o.cgm, l, h, rc);
+    at(a.reward, i) = rp - rc;
+    e.prev_cgm = o.cgm;
+    at(a.cgm, i) = o.cgm; at(a.bg, i) = o.bg;
+    at(a.done, i) = (o.bg < T(70) || o.bg > T(350)) ? 1 : 0;  // env.py:103
+    if (a.lbgi || a.hbgi || a.risk) {
+        risk_index1<MATH>(o.bg, l, h, r);                 // env.py:85
+        if (a.lbgi) at(a.lbgi, i) = l;
+        if (a.hbgi) at(a.hbgi, i) = h;
+        if (a.risk) at(a.risk, i) = r;
+    }
+    if (a.meal) at(a.meal, i) = o.meal;
+    if (a.insulin) at(a.insulin, i) = o.ins;
+    if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+}
+
+// VARIANT 0: reference arithmetic (ocml tanh, IEEE divisions), parameters from LDS
+//         1: fast arithmetic, parameters re-read from LDS per RHS evaluation (any patient layout)
+//         2: fast arithmetic, wave-uniform patient, parameters in SGPRs (T1D_BATCH_WAVE_UNIFORM)
+//         3: fast arithmetic, parameters gathered once per lane into VGPRs (any patient layout)
+//         4: as 3, split integrator (t1d_device.hpp) with the insulin propagator staged in LDS
+//         5: as 1, split integrator
+//         6, 7: as 4, 5 with the adaptive gut refinement
+template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
+template <int VARIANT> struct VariantInfo {
+    static constexpr bool split = VARIANT >= 4 && VARIANT <= 7;
+    static constexpr bool adapt = VARIANT == 6 || VARIANT == 7;
+    static constexpr bool lds_pars = VARIANT == 0 || VARIANT == 1 || VARIANT == 5 || VARIANT == 7;
+    static constexpr bool reg_pars = VARIANT == 3 || VARIANT == 4 || VARIANT == 6;
+};
+extern __shared__ __align__(16) unsigned char t1d_dyn_lds[];
+
+template <int VARIANT, typename T, bool REFILL = true>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> a)
+{
+    constexpr int MATH = VariantMath<VARIANT>::value;
+    using VI = VariantInfo<VARIANT>;
+    constexpr int kParRows = VI::split ? DP_COUNT : DP_RK4_COUNT;
+    __shared__ T lds[VI::lds_pars ? kParRows * kMaxPatients : 1];
+    if (VI::lds_pars) stage_pars(a, lds, kParRows);
+    if (VI::split) stage_prop(a, (T*)t1d_dyn_lds);
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
+    if ((int64_t)i >= a.n) return;
+    const uint32_t meta = at(a.meta, i);
+    const uint32_t pid = T1D_META_PID(meta);
+    Env<T> e;
+    load_env(a, i, meta, e);
+    const T basal = at(a.basal, i);
+    const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+    const T rp = prev_risk<MATH>(a, e.prev_cgm);
+    StepOut<T> o;
+    if constexpr (VARIANT == 4 || VARIANT == 6) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        PropLds<T, VI::adapt> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL, PropLds<T, VI::adapt>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
+    } else if constexpr (VARIANT == 5 || VARIANT == 7) {
+        ParsLds<T> p{lds, (int)pid};
+        PropLds<T, VI::adapt> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL, PropLds<T, VI::adapt>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
+    } else if constexpr (VARIANT == 2) {
+        const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
+        if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
+        ParsScalar<T> p;
+        p.load(a.dpar, kMaxPatients, pid0);
+        o = step_body<MATH, T, ParsScalar<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+    } else if constexpr (VARIANT == 3) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+    } else {
+        ParsLds<T> p{lds, (int)pid};
+        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+    }
+    write_outputs<MATH>(a, i, e, o, rp);
+    store_env(a, i, pid, e);
+}
+
+// ---- single-minute step, split integrator, persistent blocks -----------------------------------------
+// The launch the headline workload makes a million times: one simulated minute per env.step (1-min sensors),
+// no noise-block refill due (refill_kernel ran, or the host vouched).  Differences from step_kernel:
+//   * blocks are persistent (grid = what is resident) and walk tiles of 256 envs, so the parameter and
+//     propagator tables are staged into LDS once per block instead of once per 256 envs, compactly
+//     (row stride 32 or 64 patients, a compile-time constant: every table read is a ds_read with an
+//     immediate offset);
+//   * everything the integration does not need is stored BEFORE it (meal bookkeeping, clock, meal cursor,
+//     insulin/meal outputs), so that only the 13 states, the drawn noise and the previous risk are alive
+//     across the sub-step loops -- which is what lets four waves share a SIMD (<= 128 VGPRs) where
+//     step_kernel needs ~230.
+#ifndef T1D_S1_WAVES
+#define T1D_S1_WAVES 3
+#endif
+#ifndef T1D_S1_TRACE
+#define T1D_S1_TRACE 0
+#endif
+#ifndef T1D_S1_ROTATE_PRIO
+#define T1D_S1_ROTATE_PRIO 1
+#endif
+#if T1D_S1_TRACE
+// tuning builds: drain every counter and stamp the wall clock (100 MHz) at phase boundaries
+#define S1_MARK(m) do { __builtin_amdgcn_s_waitcnt(0x0070); if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + (m)] = (long long)wall_clock64(); } while (0)
+#else
+#define S1_MARK(m) do { } while (0)
+#endif
+constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a CU: T1D_S1_WAVES waves on each of its 4 SIMDs
+// EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
+// third risk evaluation drop out of the kernel altogether
+template <bool REG, typename T, int STRIDE, bool EXTRA, bool ADAPT>
+__global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
+{
+    // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
+    // prev_cgm and the 26 noise rows; rows 1, 2 of the t buffer are meta and next_meal.  Deriving them from two
+    // base pointers instead of reading ten more kernel arguments keeps the scalar registers from spilling.
+    T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
+    T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
+    __shared__ int queue;
+    __shared__ T lconst[8];                              // pump and sensor limits: read from LDS where used, so that they
+                                                         // do not sit in (spilled) scalar registers across the whole kernel
+    for (int j = threadIdx.x; j < DP_COUNT * STRIDE; j += kS1Threads) {
+        const int r = j / STRIDE, c = j % STRIDE;
+        ldp[j] = c < a.np ? a.dpar[r * kMaxPatients + c] : T(0);
+    }
+    for (int j = threadIdx.x; j < a.prop_rows * STRIDE; j += kS1Threads) {
+        const int r = j / STRIDE, c = j % STRIDE;
+        lpr[j] = c < a.np ? a.prop[r * a.np_pad + c] : T(0);
+    }
+    if (threadIdx.x == 0) {
+        queue = 0;
+        lconst[0] = a.pump.inc_basal; lconst[1] = a.pump.min_basal; lconst[2] = a.pump.max_basal;
+        lconst[3] = a.pump.inc_bolus; lconst[4] = a.pump.min_bolus; lconst[5] = a.pump.max_bolus;
+        lconst[6] = a.sen.vmin; lconst[7] = a.sen.vmax;
+    }
+    __syncthreads();
+    // This workgroup owns a contiguous run of 64-env chunks; its waves draw them from a queue in LDS.  The
+    // SIMD issues oldest-wave-first, so with a fixed share per wave the first wave of a SIMD would race ahead
+    // and the last would finish alone (measured: 66 vs 93 us); with the queue the fast wave simply takes more.
+    const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int first = (int)blockIdx.x * per_block;
+    const int count = nchunks - first < per_block ? nchunks - first : per_block;
+    const unsigned lane = threadIdx.x & 63u;
+#if T1D_S1_TRACE
+    long long* tr = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (kS1Threads / 64) + threadIdx.x / 64) * 64 : nullptr;
+    int tk = -1;
+#endif
+    for (int it = 0;; ++it) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&queue, 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= count) break;                              // wave-uniform
+        const unsigned i = (unsigned)(first + c) * 64u + lane;
+        __builtin_assume(i < (1u << 28));
+        if ((int64_t)i >= a.n) continue;
+#if T1D_S1_TRACE
+        ++tk;
+#endif
+#if T1D_S1_ROTATE_PRIO
+        // rotate the issue priority among the waves of a SIMD (waves w, w + 4, w + 8 of the workgroup) chunk by chunk
+        switch ((unsigned)(it + (int)(threadIdx.x >> 8)) % 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(2); break;
+        }
+#endif
+        S1_MARK(0);
+        const uint32_t meta = at(row(a.t, a.n, 1), i);
+        const uint32_t pid = T1D_META_PID(meta);
+        Env<T> e;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
+        e.planned = at(row(a.x, a.n, 13), i); e.lq = at(row(a.x, a.n, 14), i); e.lf = at(row(a.x, a.n, 15), i);
+        const T planned0 = e.planned, lq0 = e.lq, lf0 = e.lf;
+        e.t = at(a.t, i);
+        e.next_meal = at(row(a.t, a.n, 2), i);
+        e.next_meal_loaded = e.next_meal;
+        e.eating = (meta & T1D_META_EATING) != 0;
+        e.cursor = (int)T1D_META_CURSOR(meta);
+        const T basal = at(a.basal, i);
+        const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+        S1_MARK(1);
+        T q_basal, q_bolus;
+        if (a.flags & T1D_BATCH_NO_PUMP) {
+            q_basal = basal; q_bolus = a.bolus ? bolus : T(0);
+        } else {
+            int z = 0;
+            asm volatile("" : "+v"(z));                  // opaque index: the reads below stay inside the chunk loop
+            const T* lc = lconst + z;
+            q_basal = pump_quantise(basal, lc[0], lc[1], lc[2]);                                   // env.py:51
+            q_bolus = lc[4] > T(0) ? lc[4] : T(0);
+            if (a.bolus) q_bolus = pump_quantise(bolus, lc[3], lc[4], lc[5]);                      // env.py:52
+        }
+        const T insulin = q_basal + q_bolus;
+        const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
+        ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
+        MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+        // bookkeeping is final for this minute: store it now -- the meal words only where they changed (they do
+        // while an env is eating, ~3 % of the minutes: 24 B per env-step of write traffic otherwise)
+        if (e.planned != planned0) at(row(a.x, a.n, 13), i) = e.planned;
+        if (e.lq != lq0) at(row(a.x, a.n, 14), i) = e.lq;
+        if (e.lf != lf0) at(row(a.x, a.n, 15), i) = e.lf;
+        at(a.t, i) = e.t + 1;
+        if (e.next_meal != e.next_meal_loaded) at(row(a.t, a.n, 2), i) = e.next_meal;
+        {   // patient id, eating flag, meal cursor: changes when a meal starts, ends or fires
+            const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+            if (meta1 != meta) at(row(a.t, a.n, 1), i) = meta1;
+        }
+        if (EXTRA) {
+            if (a.meal) at(a.meal, i) = meal;
+            if (a.insulin) at(a.insulin, i) = insulin;
+        }
+        S1_MARK(2);
+        {
+            PropLdsS<T, STRIDE, ADAPT> pr{lpr, (int)pid};
+            if (REG) {
+                ParsReg<T> p;
+#pragma unroll
+                for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
+                if (ADAPT) {
+#pragma unroll
+                    for (int k = 0; k < (int)(sizeof(kAdaptPars) / sizeof(int)); ++k) p.v[kAdaptPars[k]] = pl(kAdaptPars[k]);
+                }
+                p.pin_split();
+                if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub);
+            } else {
+                if (!(a.flags & 0x800)) split_minute(pl, pr, u, e.x, a.n_sub);
+            }
+        }
+        S1_MARK(3);
+#pragma unroll
+        for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
+        // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.x, a.n, 40 + k), i);
+        // with a 1-minute sensor every minute takes a fresh sample: the held value is never read
+        T last_cgm = a.sen.st == 1 ? T(0) : (T)at(row(a.x, a.n, 16), i);
+        const T prev_cgm = at(row(a.x, a.n, 17), i);
+        S1_MARK(4);
+        bool due;
+        const T noise = measure_noise<false>(a, i, e, due);       // e.t is still the minute's start: sample for t + 1
+        const T rp = prev_risk<1>(a, prev_cgm);
+        const T gsub = e.x[12] * pl(DP_IVG);                                                       // t1dpatient.py:217-218
+        if (due) {                                                                                 // cgm.py:26-36
+            T c = gsub + noise;
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const T vmin = lconst[6 + z], vmax = lconst[7 + z];
+            c = c > vmin ? c : vmin;
+            c = c < vmax ? c : vmax;
+            last_cgm = c;
+            if (a.sen.st != 1) at(row(a.x, a.n, 16), i) = c;      // the zero-order hold is dead state with a 1-minute sensor
+        }
+        T l, h, r, rc = T(0);
+        if (!(a.flags & 0x100)) risk_index1<1>(last_cgm, l, h, rc);
+        at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
+        at(row(a.x, a.n, 17), i) = last_cgm;
+        at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
+        at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
+        if (EXTRA && (a.lbgi || a.hbgi || a.risk)) {
+            risk_index1<1>(gsub, l, h, r);                                                         // env.py:85
+            if (a.lbgi) at(a.lbgi, i) = l;
+            if (a.hbgi) at(a.hbgi, i) = h;
+            if (a.risk) at(a.risk, i) = r;
+        }
+        if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+#if T1D_S1_TRACE
+        if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + 5] = (long long)wall_clock64();    // epilogue computed, stores issued
+#endif
+        S1_MARK(6);
+    }
+}
+
+// ---- persistent, software-pipelined step ---------------------------------------------------------
+// One-tile-per-block launches keep the two waves of a SIMD in lock-step: both wait for their loads,
+// then both compete for the VALU, then both store, so the chip alternates between an idle VALU and an
+// idle memory system (measured: ~60-90 us of a 150-170 us launch at 1 Mi envs).  Here each block walks
+// tiles blockIdx.x, +gridDim.x, ... and every wave streams the state of its NEXT 64 envs from HBM
+// straight into a wave-private LDS staging area with LDS-DMA (global_load_lds_dwordx4: no VGPR is
+// held by data in flight) while it integrates the current 64.  Nothing but the issuing wave's vmcnt
+// orders a ds_read behind a pending LDS-DMA, hence the explicit waits.
+typedef __attribute__((address_space(1))) const void t1d_gptr;
+typedef __attribute__((address_space(3))) void t1d_lptr;
+
+// The pipelined kernel needs the per-env state PACKED: one [44][n] buffer of T (rows 0-12 x, 13 planned,
+// 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_cgm, 18-43 pts) and one [3+][n] int buffer (t, meta,
+// next_meal), so that every staged row is `base + 32-bit offset` (t1d_step checks the pointers and
+// falls back to step_kernel otherwise).  Stage rows: 0-17 = state rows 0-17, 18-21 = pts rows 22-25
+// (state rows 40-43), 22.. = basal, 22+G.. = bolus (each DMA group fetches G rows: 2 for double, 4 for float).
+constexpr int kPackedRows = 18 + kPtsRows;            // 44
+template <typename T> struct StageGeom {
+    static constexpr int EPL = 16 / (int)sizeof(T);   // elements per lane per DMA
+    static constexpr int LPR = 64 / EPL;              // lanes per 64-element row
+    static constexpr int G = 64 / LPR;                // rows per DMA instruction (2 / 4)
+    static constexpr int BASAL = 24;                  // first stage row of the basal group
+    static constexpr int BOLUS = BASAL + G;
+    static constexpr int ROWS = BOLUS + G;
+};
+template <typename T> struct Stage {
+    T f[StageGeom<T>::ROWS][64];
+    int i[4][64];
+};
+
+// One LDS-DMA: lane l fetches 16 B at base + voff; the 1 KiB lands contiguously at lds_dst (M0).
+// Issued through inline asm on purpose: when hipcc knows about a pending LDS-DMA it puts an
+// `s_waitcnt vmcnt(0)` in front of EVERY later LDS read (here: the parameter table inside the RK4
+// loop), which serialises the prefetch with the arithmetic it is meant to hide under.  The loop in
+// step_pipe_kernel counts and waits for these operations itself.
+__device__ __forceinline__ void dma16(const void* base_uniform, unsigned voff, void* lds_dst)
+{
+    const unsigned lds_addr = (unsigned)(size_t)(t1d_lptr*)lds_dst;
+    unsigned saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "v"(voff), "s"(base_uniform), "s"(lds_addr) : "memory");
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_tile(const KArgs<T>& a, unsigned elem0, Stage<T>* st)
+{
+    using GEO = StageGeom<T>;
+    unsigned lane = threadIdx.x & 63u;
+    asm volatile("" : "+v"(lane));       // recompute the few offsets here: hoisted out of the tile loop they get spilled,
+                                         // and a scratch reload between two DMAs is a vmcnt(0) that waits for the first
+    const unsigned rowb = (unsigned)a.n * (unsigned)sizeof(T);                       // bytes per state row
+    const unsigned v0 = elem0 * (unsigned)sizeof(T) + (lane / GEO::LPR) * rowb + (lane % GEO::LPR) * 16u;
+    const void* xb = a.x;
+#pragma unroll
+    for (int r = 0; r < 18; r += GEO::G) dma16(xb, v0 + (unsigned)r * rowb, &st->f[r][0]);   // rows 0..17 (+ spill-over into 18, 19 for float)
+#pragma unroll
+    for (int r = 0; r < 4; r += GEO::G) dma16(xb, v0 + (unsigned)(40 + r) * rowb, &st->f[20 + r][0]);
+    const unsigned vsame = elem0 * (unsigned)sizeof(T) + (lane % GEO::LPR) * 16u;  // every row group = the same row
+    dma16(a.basal, vsame, &st->f[GEO::BASAL][0]);
+    if (a.bolus) dma16(a.bolus, vsame, &st->f[GEO::BOLUS][0]);
+    const unsigned rowi = (unsigned)a.n * 4u;
+    const unsigned li = lane / 16u;
+    dma16(a.t, elem0 * 4u + (li < 3u ? li : 0u) * rowi + (lane % 16u) * 16u, &st->i[0][0]);
+}
+
+template <typename T>
+__device__ __forceinline__ void unstage(const KArgs<T>& a, const Stage<T>* st, Env<T>& e, T& basal, T& bolus, uint32_t& meta)
+{
+    using GEO = StageGeom<T>;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) e.x[k] = st->f[k][lane];
+    e.planned = st->f[13][lane]; e.lq = st->f[14][lane]; e.lf = st->f[15][lane];
+    e.last_cgm = st->f[16][lane]; e.prev_cgm = st->f[17][lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.cur[k] = st->f[20 + k][lane];
+    basal = st->f[GEO::BASAL][lane];
+    bolus = a.bolus ? st->f[GEO::BOLUS][lane] : T(0);
+    e.t = st->i[0][lane];
+    meta = (uint32_t)st->i[1][lane];
+    e.next_meal = st->i[2][lane];
+    e.next_meal_loaded = e.next_meal;
+    e.eating = (meta & T1D_META_EATING) != 0;
+    e.cursor = (int)T1D_META_CURSOR(meta);
+}
+
+// requires a.n % kBlock == 0 and the packed state layout (the host falls back to step_kernel otherwise)
+template <int VARIANT, typename T>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void step_pipe_kernel(const KArgs<T> a)
+{
+    constexpr int MATH = 1;
+    __shared__ T lds[VARIANT == 2 ? 1 : DP_RK4_COUNT * kMaxPatients];
+    __shared__ Stage<T> stage[kBlock / 64];
+    if (VARIANT != 2) stage_pars(a, lds, DP_RK4_COUNT);
+    const unsigned ntiles = (unsigned)(a.n / kBlock);
+    unsigned tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Stage<T>* st = &stage[wave];
+    // Identical waves that start together stay in lock-step: both waves of a SIMD are in their latency-bound
+    // prologue/epilogue at the same time and in the VALU-dense RK4 loop at the same time.  Delaying the
+    // second half of the grid (the second workgroup of each CU under round-robin dispatch) by a fraction
+    // of a tile puts the pairs out of phase for the rest of the launch.
+    if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2)
+        for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    stage_tile(a, tile * kBlock + (unsigned)wave * 64u, st);
+    bool first = true;
+    for (;;) {
+        const unsigned i = tile * kBlock + threadIdx.x;
+        __builtin_assume(i < (1u << 28));
+        Env<T> e;
+        T basal, bolus;
+        uint32_t meta;
+        // This tile's DMA must have landed.  vmcnt retires in order and the DMA is OLDER than everything the
+        // previous tile issued afterwards, of which at least kTileStores are unconditional stores
+        // (x[13], planned, last_qsto, last_food, last_cgm, prev_cgm, t, meta, cgm, bg, reward, done): once
+        // at most that many operations are outstanding the DMA is complete, and the wave does not sit
+        // through the write burst of its own stores.
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        unstage(a, st, e, basal, bolus, meta);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging area read out before it is refilled
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned ntile = tile + gridDim.x;
+        const bool more = ntile < ntiles;
+        const unsigned next_elem0 = ntile * kBlock + (unsigned)wave * 64u;
+        auto prefetch = [&]() {
+            if (more) stage_tile(a, next_elem0, st);      // in flight while this tile integrates
+        };
+        const uint32_t pid = T1D_META_PID(meta);
+        const T rp = prev_risk<MATH>(a, e.prev_cgm);
+        StepOut<T> o;
+        if (VARIANT == 2) {
+            const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
+            if (__ballot((int)pid != pid0) != 0ull) {
+                atomicOr(a.status, T1D_ST_BAD_LAYOUT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                break;                                   // no stores were issued: the counted wait above would not hold
+            }
+            ParsScalar<T> p;
+            p.load(a.dpar, kMaxPatients, pid0);
+            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
+            write_outputs<MATH>(a, i, e, o, rp);
+            store_env(a, i, pid, e);
+        } else if (VARIANT == 3) {
+            ParsReg<T> p;
+            p.load(lds, (int)pid);                       // 38 ds_reads per tile, then no LDS traffic in the RK4 loop
+            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
+            write_outputs<MATH>(a, i, e, o, rp);
+            store_env(a, i, pid, e);
+        } else {
+            ParsLds<T> p{lds, (int)pid};
+            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
+            write_outputs<MATH>(a, i, e, o, rp);
+            store_env(a, i, pid, e);
+        }
+        if (!more) break;
+        tile = ntile;
+        first = false;
+    }
+}
+
+// Rebuilds the CGM noise block of every env whose next sample(s) -- in minutes (t, t + minutes] -- start a
+// new 150-minute block.  Launched by t1d_step ahead of step_kernel<.., REFILL = false>; touches 4 B per env
+// (the clock) unless a refill is due, which happens once per 150 simulated minutes per env.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void refill_kernel(const KArgs<T> a)
+{
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));
+    if ((int64_t)i >= a.n) return;
+    const int t = at(a.t, i);
+    for (int m = 1; m <= a.minutes; ++m) {
+        const int t1 = t + m;
+        int q, r, blk, j;
+        divmod_uniform(t1, a.sen.st, q, r);
+        if (r != 0) continue;
+        divmod_uniform(1 + q, a.S, blk, j);
+        if (j != 0) continue;
+        T e = at(a.ar_e, i);
+        noise_refill<T>(a.pts, a.normals, a.minv, a.episode, a.status, a.n, i, a.env_offset, a.seed, a.n_normals, blk, a.sen, &e);
+        at(a.ar_e, i) = e;
+    }
+}
+
+template <int VARIANT, typename T, typename P, typename PR = NoProp>
+__device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>& c, P& p, unsigned i, uint32_t pid, Env<T>& e, PR pr = PR())
+{
+    constexpr int MATH = VariantMath<VARIANT>::value;
+    T obs = at(a.cgm, i);
+    const bool bb = c.kind == 1;
+    T integ = T(0), prev = T(0), bb_basal = T(0), bb_cr = T(1), bb_cf = T(1), prev_meal = T(0);
+    if (bb) { bb_basal = at(c.bb_basal, i); bb_cr = at(c.bb_cr, i); bb_cf = at(c.bb_cf, i); prev_meal = at(c.bb_prev_meal, i); }
+    else { integ = at(c.integ, i); prev = at(c.prev, i); }
+    T sum_risk = c.sum_risk ? at(c.sum_risk, i) : T(0);
+    T min_bg = c.min_bg ? at(c.min_bg, i) : T(0), max_bg = c.max_bg ? at(c.max_bg, i) : T(0);
+    int n_low = c.n_low ? at(c.n_low, i) : 0, n_high = c.n_high ? at(c.n_high, i) : 0;
+    const T st = T(a.sen.st);
+    StepOut<T> o{obs, T(0), T(0), T(0)};
+    T pre_prev_cgm = e.prev_cgm;
+    for (int s = 0; s < c.n_steps; ++s) {
+        T u, bolus = T(0);
+        if (bb) {
+            // BBController._bb_policy (basal_bolus_ctrller.py:64-79)
+            u = bb_basal;
+            if (prev_meal > T(0)) {
+                const T corr = obs > T(150) ? (obs - c.target) / bb_cf : T(0);
+                bolus = ((prev_meal * st) / bb_cr + corr) / st;
+            }
+        } else {
+            // PIDController.policy (pid_ctrller.py:17-36)
+            u = c.P * (obs - c.target) + c.I * integ + c.D * (obs - prev) / st;
+            prev = obs;
+            integ += (obs - c.target) * st;
+        }
+        o = step_body<MATH, T, P, NoHook, false, true, PR>(a, p, i, e, u, bolus, true, NoHook(), pr);
+        obs = o.cgm;
+        prev_meal = o.meal;
+        if (c.bg_trace) c.bg_trace[(c.trace_row + s) * a.n + i] = o.bg;
+        if (c.cgm_trace) c.cgm_trace[(c.trace_row + s) * a.n + i] = o.cgm;
+        if (c.cho_trace) c.cho_trace[(c.trace_row + s) * a.n + i] = o.meal;
+        if (c.ins_trace) c.ins_trace[(c.trace_row + s) * a.n + i] = o.ins;
+        pre_prev_cgm = e.prev_cgm;
+        e.prev_cgm = o.cgm;                      // CGM history advances every step
+        if (c.sum_risk) { T l, h, r; risk_index1<MATH>(o.bg, l, h, r); sum_risk += r; }
+        min_bg = o.bg < min_bg ? o.bg : min_bg;
+        max_bg = o.bg > max_bg ? o.bg : max_bg;
+        n_low += o.bg < T(70); n_high += o.bg > T(180);
+    }
+    e.prev_cgm = pre_prev_cgm;                   // the last step's reward is formed from it
+    write_outputs<MATH>(a, i, e, o, prev_risk<MATH>(a, pre_prev_cgm));
+    store_env(a, i, pid, e);
+    if (bb) at(c.bb_prev_meal, i) = prev_meal;
+    else { at(c.integ, i) = integ; at(c.prev, i) = prev; }
+    if (c.sum_risk) at(c.sum_risk, i) = sum_risk;
+    if (c.min_bg) at(c.min_bg, i) = min_bg;
+    if (c.max_bg) at(c.max_bg, i) = max_bg;
+    if (c.n_low) at(c.n_low, i) = n_low;
+    if (c.n_high) at(c.n_high, i) = n_high;
+}
+
+template <int VARIANT, typename T>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void rollout_pid_kernel(const KArgs<T> a, const PidArgs<T> c)
+{
+    using VI = VariantInfo<VARIANT>;
+    constexpr int kParRows = VI::split ? DP_COUNT : DP_RK4_COUNT;
+    __shared__ T lds[VI::lds_pars ? kParRows * kMaxPatients : 1];
+    if (VI::lds_pars) stage_pars(a, lds, kParRows);
+    if (VI::split) stage_prop(a, (T*)t1d_dyn_lds);
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
+    if ((int64_t)i >= a.n) return;
+    const uint32_t meta = at(a.meta, i);
+    const uint32_t pid = T1D_META_PID(meta);
+    Env<T> e;
+    load_env(a, i, meta, e);
+    if constexpr (VARIANT == 4 || VARIANT == 6) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T, VI::adapt>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+    } else if constexpr (VARIANT == 5 || VARIANT == 7) {
+        ParsLds<T> p{lds, (int)pid};
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T, VI::adapt>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+    } else if constexpr (VARIANT == 2) {
+        const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
+        if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
+        ParsScalar<T> p;
+        p.load(a.dpar, kMaxPatients, pid0);
+        rollout_body<VARIANT>(a, c, p, i, pid, e);
+    } else if constexpr (VARIANT == 3) {
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        rollout_body<VARIANT>(a, c, p, i, pid, e);
+    } else {
+        ParsLds<T> p{lds, (int)pid};
+        rollout_body<VARIANT>(a, c, p, i, pid, e);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const uint8_t* mask, int random_init_bg)
+{
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));          // host guarantees n <= 2^28: i * sizeof(T) fits a 32-bit voffset
+    if ((int64_t)i >= a.n) return;
+    if (mask && !at(mask, i)) return;
+    const int64_t n = a.n;
+    const uint32_t pid = T1D_META_PID(at(a.meta, i));
+    uint32_t ep = 0;
+    if (a.episode) { ep = at(a.episode, i) + 1u; at(a.episode, i) = ep; }
+    const uint64_t gid = (uint64_t)(a.env_offset + i);
+    Env<T> e;
+    // T1DPatient.reset (t1dpatient.py:247-281)
+#pragma unroll
+    for (int k = 0; k < 13; ++k)
+        e.x[k] = a.x0_override ? at(row(a.x0_override, n, k), i) : (T)a.x0tab[k * a.np + pid];
+    if (random_init_bg && !a.x0_override) {          // :256-270, statistical counterpart
+        const double2 r1 = philox_pair(a.seed, gid, ep, 1u), r2 = philox_pair(a.seed, gid, ep, 2u);
+        e.x[3] += t_sqrt(T(0.1) * e.x[3]) * (T)r1.x;
+        e.x[4] += t_sqrt(T(0.1) * e.x[4]) * (T)r1.y;
+        e.x[12] += t_sqrt(T(0.1) * e.x[12]) * (T)r2.x;
+    }
+    e.planned = T(0); e.lq = e.x[0] + e.x[1]; e.lf = T(0); e.eating = false; e.cursor = 0; e.t = 0;
+    e.next_meal = (a.n_meals > 0) ? at(a.meal_time, i) : INT_MAX;      // first table row; entries before t = 0 are skipped lazily
+    e.next_meal_loaded = e.next_meal - 1;                               // force the store
+    // CGMSensor.reset -> CGMNoise(): first AR value and first 15-min point (noise_gen.py:24,86)
+    T z0;
+    if (a.normals) {
+        if (a.n_normals > 0) z0 = at(a.normals, i); else { z0 = T(0); atomicOr(a.status, T1D_ST_NORMALS_EXHAUSTED); }
+    } else {
+        z0 = (T)philox_pair(a.seed, gid, ep, 0u).x;
+    }
+    at(a.ar_e, i) = z0;
+    at(a.pts, i) = johnson_su<true>(a.sen, z0);
+    e.last_cgm = T(0);
+    const T vg = a.dpar[DP_VG * kMaxPatients + pid];
+    const T bg0 = e.x[12] / vg;
+    T c[2];
+    for (int s = 0; s < 2; ++s) {                    // env.py:126 (history[0]) and env.py:142 (observation)
+        T v = bg0 + noise_sample<true>(a, i, s, e.cur);
+        v = v > a.sen.vmin ? v : a.sen.vmin;
+        v = v < a.sen.vmax ? v : a.sen.vmax;
+        c[s] = v;
+    }
+    e.last_cgm = c[1];
+    e.prev_cgm = c[0];
+    store_env(a, i, pid, e);
+    T l, h, r;
+    risk_index1<0>(bg0, l, h, r);
+    at(a.cgm, i) = c[1]; at(a.bg, i) = bg0; at(a.reward, i) = T(0); at(a.done, i) = 0;
+    if (a.lbgi) at(a.lbgi, i) = l;
+    if (a.hbgi) at(a.hbgi, i) = h;
+    if (a.risk) at(a.risk, i) = r;
+    if (a.meal) at(a.meal, i) = T(0);
+    if (a.insulin) at(a.insulin, i) = T(0);
+}
+
+__global__ void philox_normals_kernel(uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,
+                                      int draw0, int n_draws, double* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t gid = (uint64_t)(env_offset + i);
+    for (int r = 0; r < n_draws; ++r) {
+        const int d = draw0 + r;
+        uint32_t pair; int el;
+        if (d < 0) { const int q = d + 3; pair = 1u + (uint32_t)(q / 2); el = q & 1; }     // random_init_bg normals
+        else if (d == 0) { pair = 0u; el = 0; }
+        else { const int k = (d - 1) % 10, b = (d - 1) / 10; pair = 3u + 5u * (uint32_t)b + (uint32_t)(k / 2); el = k & 1; }
+        const double2 v = philox_pair(seed, gid, episode, pair);
+        out[(int64_t)r * n + i] = el ? v.y : v.x;
+    }
+}
+
+
+// ---- RandomScenario.create_scenario for a whole batch (simulation/scenario_gen.py:33-60) ----------------
+// One lane = one env: for each calendar day the episode touches, six candidate meals with presence
+// probabilities (.95,.3,.95,.3,.95,.3), truncated-normal times of day (inverse-CDF sampling between the
+// window bounds, rounded to the minute) and max(round(N(mu, sigma)), 0) grams.  The windows are contiguous
+// and increasing, so a day's meals come out in time order; a meal landing on the minute of the one before it
+// (window boundary) is dropped, as the reference's dict-by-time scenario keeps one entry per minute.
+// Statistical counterpart of the reference (numpy's MT19937 stream is not reproduced); Philox subsequence =
+// global env id, two blocks per candidate meal, in a key domain of its own (seed ^ kScenarioKey).
+struct MealSlots {
+    double prob[6], lb[6], ub[6], mu[6], sd[6], amu[6], asd[6], cdf_a[6], cdf_w[6];
+};
+constexpr uint64_t kScenarioKey = 0x5ce9a7105ce9a710ull;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void random_meals_kernel(uint64_t seed, int64_t env_offset, int64_t n, int days,
+                                                              const int32_t* start_tab, int start_scalar,
+                                                              int32_t* meal_time, T* meal_amt, MealSlots ms)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int rows = 6 * (days + 1);
+    const int start = start_tab ? start_tab[i] : start_scalar;
+    const uint64_t gid = (uint64_t)(env_offset + i);
+    int w = 0, last = -1;
+    for (int day = 0; day <= days; ++day) {
+#pragma unroll 1
+        for (int k = 0; k < 6; ++k) {
+            rocrand_state_philox4x32_10 st;
+            rocrand_init(seed ^ kScenarioKey, gid, 8ull * (unsigned long long)(day * 6 + k), &st);
+            const double2 u = rocrand_uniform_double2(&st);           // (0, 1]
+            const double2 g = rocrand_normal_double2(&st);
+            const bool present = u.x <= ms.prob[k];                    // rand() < p            (:48)
+            double q = ms.cdf_a[k] + u.y * ms.cdf_w[k];               // truncnorm.rvs          (:50-54)
+            q = fmin(fmax(2.0 * q - 1.0, -1.0 + 1e-15), 1.0 - 1e-15);
+            double tod = rint(ms.mu[k] + ms.sd[k] * 1.4142135623730951 * erfinv(q));   // np.round (:49)
+            tod = fmin(fmax(tod, ms.lb[k]), ms.ub[k]);
+            const double grams = fmax(rint(ms.amu[k] + ms.asd[k] * g.x), 0.0);          // :56-57
+            const int minute = day * 1440 + (int)tod - start;
+            if (present && minute >= 0 && minute < days * 1440 && minute != last) {
+                meal_time[(int64_t)w * n + i] = minute;
+                meal_amt[(int64_t)w * n + i] = (T)grams;
+                last = minute; ++w;
+            }
+        }
+    }
+    for (; w < rows; ++w) { meal_time[(int64_t)w * n + i] = INT_MAX; meal_amt[(int64_t)w * n + i] = T(0); }
+}
+
+// ---- outcome statistics of a BG history on the device (analysis/report.py) ------------------------------
+// One lane = one env, rows are read coalesced.  The two percentiles are exact: the order statistics are found
+// by radix selection on the order-preserving integer image of the values (one pass over the env's column per
+// bit), then interpolated as numpy's default 'linear' method does.
+template <typename T> struct OKey;
+template <> struct OKey<double> {
+    typedef uint64_t U; static constexpr int bits = 64;
+    static __device__ __forceinline__ U key(double v) { const U u = (U)__double_as_longlong(v); return (u >> 63) ? ~u : (u | 0x8000000000000000ull); }
+    static __device__ __forceinline__ double val(U k) { const U u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k; return __longlong_as_double((long long)u); }
+};
+template <> struct OKey<float> {
+    typedef uint32_t U; static constexpr int bits = 32;
+    static __device__ __forceinline__ U key(float v) { const U u = __float_as_uint(v); return (u >> 31) ? ~u : (u | 0x80000000u); }
+    static __device__ __forceinline__ float val(U k) { const U u = (k >> 31) ? (k & 0x7fffffffu) : ~k; return __uint_as_float(u); }
+};
+
+// k-th smallest (0-based) of column i, and the next order statistic after it
+template <typename T>
+__device__ void order_stat_pair(const T* __restrict__ tr, int64_t n, int64_t rows, int64_t i, int64_t k, T& vk, T& vk1)
+{
+    typedef typename OKey<T>::U U;
+    U prefix = 0;
+    for (int bit = OKey<T>::bits - 1; bit >= 0; --bit) {
+        const U test = prefix | ((U)1 << bit);
+        int64_t c = 0;
+        for (int64_t r = 0; r < rows; ++r) c += OKey<T>::key(tr[r * n + i]) < test;
+        if (c <= k) prefix = test;
+    }
+    int64_t le = 0; U next = ~(U)0; bool have = false;
+    for (int64_t r = 0; r < rows; ++r) {
+        const U key = OKey<T>::key(tr[r * n + i]);
+        le += key <= prefix;
+        if (key > prefix && (!have || key < next)) { next = key; have = true; }
+    }
+    vk = OKey<T>::val(prefix);
+    vk1 = (le > k + 1 || !have) ? vk : OKey<T>::val(next);      // duplicates of the k-th value cover rank k + 1
+}
+
+template <typename T>
+__device__ __forceinline__ T percentile_linear(const T* tr, int64_t n, int64_t rows, int64_t i, double q)
+{
+    const double pos = (double)(rows - 1) * q / 100.0;
+    int64_t lo = (int64_t)floor(pos);
+    lo = lo < 0 ? 0 : (lo > rows - 1 ? rows - 1 : lo);
+    const double t = pos - (double)lo;
+    T a, b;
+    order_stat_pair(tr, n, rows, i, lo, a, b);
+    if (lo >= rows - 1) b = a;
+    const double d = (double)b - (double)a;                       // numpy _lerp
+    double r = (double)a + d * t;
+    if (t >= 0.5) r = (double)b - d * (1.0 - t);
+    if (b == a) r = (double)a;
+    return (T)r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void outcome_kernel(int64_t n, int64_t rows, const T* __restrict__ tr, int32_t* counts,
+                                                         T* pct, uint8_t* zone, T* risk_trace, double q_lo, double q_hi, int chunk)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (counts || risk_trace) {
+        int c180 = 0, c70 = 0, cin = 0, c250 = 0, c50 = 0;
+        double fsum = 0.0; int fcnt = 0; int64_t ch = 0;
+        for (int64_t r = 0; r < rows; ++r) {
+            const T bg = tr[r * n + i];
+            c180 += bg > T(180); c70 += bg < T(70); cin += (bg >= T(70)) & (bg <= T(180)); c250 += bg > T(250); c50 += bg < T(50);
+            if (risk_trace) {
+                if (bg > T(0)) { fsum += 1.509 * (pow(log((double)bg), 1.084) - 5.381); ++fcnt; }      // report.py:98-100
+                if ((r + 1) % chunk == 0 || r == rows - 1) {
+                    const double f = fcnt ? fsum / (double)fcnt : __builtin_nan("");
+                    const double fl = f < 0.0 ? f : 0.0, fh = f > 0.0 ? f : 0.0;                        // report.py:104-105
+                    risk_trace[(ch * 2) * n + i] = (T)(f == f ? 10.0 * fl * fl : f);
+                    risk_trace[(ch * 2 + 1) * n + i] = (T)(f == f ? 10.0 * fh * fh : f);
+                    fsum = 0.0; fcnt = 0; ++ch;
+                }
+            }
+        }
+        if (counts) { counts[i] = c180; counts[n + i] = c70; counts[2 * n + i] = cin; counts[3 * n + i] = c250; counts[4 * n + i] = c50; }
+    }
+    if (pct || zone) {
+        const T plo = percentile_linear(tr, n, rows, i, q_lo), phi = percentile_linear(tr, n, rows, i, q_hi);
+        if (pct) { pct[i] = plo; pct[n + i] = phi; }
+        if (zone) {                                                     // CVGA_analysis (report.py:198-217)
+            double mn = (double)plo, mx = (double)phi;
+            mn = mn < 50.0 ? 50.0 : (mn > 400.0 ? 400.0 : mn);
+            mx = mx < 50.0 ? 50.0 : (mx > 400.0 ? 400.0 : mx);
+            const bool A = mn > 90 && mn <= 110 && mx >= 110 && mx < 180;
+            const bool B = mn > 70 && mn <= 110 && mx >= 110 && mx < 300;
+            const bool Cz = (mn > 90 && mn <= 110 && mx >= 300) || (mn <= 70 && mx >= 110 && mx < 180);
+            const bool D = (mn > 70 && mn <= 90 && mx >= 300) || (mn <= 70 && mx >= 180 && mx < 300);
+            const bool E = mn <= 70 && mx >= 300;
+            zone[i] = A ? 0 : (B ? 1 : (Cz ? 2 : (D ? 3 : (E ? 4 : 5))));
+        }
+    }
+}
+
+} // namespace t1d
