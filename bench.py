@@ -67,6 +67,11 @@ def main():
     ap.add_argument("--integrator", choices=("auto", "rk4", "split"), default="auto")
     ap.add_argument("--fixed-step", action="store_true",
                     help="switch off the split integrator's adaptive gut refinement (the library default keeps it on: DESIGN.md section 4)")
+    ap.add_argument("--midnight-start", action="store_true",
+                    help="start every episode at 00:00 (default: a random minute of the day per env, like the reference's gym "
+                         "wrapper draws a random start hour, so that every launch sees the day's mix of meal phases)")
+    ap.add_argument("--in-place", action="store_true",
+                    help="adaptive refinement in place (adaptive_gut = 2) instead of deferred to the end of the launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
@@ -114,11 +119,13 @@ def main():
                            env_offset=rank * n, noise="philox", extra_outputs=False)
     env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
     integ = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else "split"
-    env.set_option("adaptive_gut", 0 if a.fixed_step else 1)
+    env.set_option("adaptive_gut", 0 if a.fixed_step else (2 if a.in_place else 1))
     if integ == "split" and not a.fixed_step:
         integ = "split_adaptive"
     days = 1 + (a.steps + a.warmup) * env.minutes_per_step // 1440
-    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=0, seed=1000, device=dev, dtype=dt, env_offset=rank * n)
+    gs = torch.Generator(device=dev); gs.manual_seed(99 + rank)
+    start_min = 0 if a.midnight_start else torch.randint(0, 1440, (n,), generator=gs, device=dev, dtype=torch.int32)
+    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=start_min, seed=1000, device=dev, dtype=dt, env_offset=rank * n)
     env.set_meals(mt, ma)
     basal0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, dtype=dt, device=dev)
     g = torch.Generator(device=dev); g.manual_seed(7 + rank)
@@ -159,12 +166,20 @@ def main():
     sane = bool(torch.isfinite(bg).all()) and status == 0
 
     if rank == 0:
+        tname = "double" if a.dtype == "f64" else "float"
+        if integ != "rk4" and minutes == 1:
+            kernel_name = {"split": "t1d::step1_kernel<true, %s, 32, false, false>",
+                           "split_adaptive": "t1d::step1_kernel<false, %s, 32, false, true>" if a.in_place
+                                             else "t1d::step1d_kernel<true, %s, 32, false>"}[integ] % tname
+        else:
+            kernel_name = "t1d::step_kernel<%d, %s, false>" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname)
         traffic = a.traffic_bytes
         if traffic is None:                               # last recorded PMC measurement of this exact configuration
             try:
                 with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
                     tj = json.load(f)
-                if (tj["envs"], tj["dtype"], tj["n_sub"], tj["minutes"], tj.get("integrator", "rk4")) == (n, a.dtype, a.n_sub, minutes, integ):
+                if (tj["envs"], tj["dtype"], tj["n_sub"], tj["minutes"], tj.get("integrator", "rk4"), tj.get("kernel", "")) == \
+                        (n, a.dtype, a.n_sub, minutes, integ, kernel_name):
                     traffic = tj["traffic_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 traffic = None
@@ -176,13 +191,11 @@ def main():
             "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "configs[3]: %d envs per GPU, patient=i mod 30, random-action policy, "
-                                   "random meal tables, %s sensor (sample_time %d min), %s integrator n_sub=%d, Philox CGM noise"
-                                   % (n, a.sensor, minutes, integ, a.n_sub),
+                                   "random meal tables (episodes start at %s), %s sensor (sample_time %d min), %s integrator n_sub=%d, Philox CGM noise"
+                                   % (n, "00:00" if a.midnight_start else "a random minute of the day per env", a.sensor, minutes, integ, a.n_sub),
                        "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": ({"split": "t1d::step1_kernel<true, %s, 32, false, false>", "split_adaptive": "t1d::step1_kernel<false, %s, 32, false, true>"}[integ]
-                                    if integ != "rk4" and minutes == 1 else
-                                    "t1d::step_kernel<%d, %s, false>" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], "%s")) % ("double" if a.dtype == "f64" else "float"),
+                         "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),

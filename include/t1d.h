@@ -225,7 +225,9 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * "adaptive_gut": 1 = the split integrator takes two gut steps of half the size in the minutes in which an
  * argument of the gastric-emptying tanh pair (t1dpatient.py:138-140) moves fast through its transition (< 1 % of
  * the env-minutes of a RandomScenario day: steep patients after large meals), which is where fixed steps lose
- * accuracy; the error against a tight solve then equals that of n_sub doubled, for ~20 % more time.  Default 1;
+ * accuracy; the error against a tight solve then equals that of n_sub doubled.  Default 1: in one-minute launches
+ * the flagged envs are set aside and integrated together at the end of the launch (+6 % time at 1 Mi envs), in
+ * multi-minute launches and roll-outs they take their extra steps in place (~+20 %); 2 = in place everywhere;
  * 0 = the same steps in every minute. */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 

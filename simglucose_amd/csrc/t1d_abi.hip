@@ -31,6 +31,8 @@ struct t1d_ctx {
     int params_mode = -1;    // 0 = LDS re-read per RHS evaluation, 1 = gathered once into VGPRs, -1 = by minutes per launch
     int pipeline = 0;        // 1 = persistent LDS-DMA pipelined step kernel, 0 = one tile per block
     int n_cu = 256;
+    int lds_per_block = 65536;   // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
+    std::vector<const void*> lds_allowed;   // kernels whose dynamic-LDS ceiling has been raised above 64 KiB
     int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
     int split_refill = 1;    // 1 = noise-block refills run in their own kernel ahead of a refill-free step kernel
     int pipe_stagger = 0;    // s_sleep(127) iterations (~3.4 us each) by which the second half of the persistent grid starts late
@@ -264,6 +266,8 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
 
         t1d_ctx* c = new (std::nothrow) t1d_ctx();
         if (!c) return fail(T1D_E_INVALID, "t1d_ctx_create: out of host memory");
+        int lds_max = 0;
+        if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, hip_device) == hipSuccess && lds_max > 0) c->lds_per_block = lds_max;
         c->device = hip_device; c->n_cu = n_cu > 0 ? n_cu : 256; c->np = n_patients; c->S = (int)std::floor(150.0 / st);   // noise_gen.py:41-42
         std::memcpy(c->sensor, sensor_row, sizeof(c->sensor));
         std::memcpy(c->pump, pump_row, sizeof(c->pump));
@@ -363,7 +367,7 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         return T1D_OK;
     }
     if (std::strcmp(name, "adaptive_gut") == 0) {
-        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: adaptive_gut must be 0 or 1");
+        if (value < 0 || value > 2) return fail(T1D_E_INVALID, "t1d_ctx_set_option: adaptive_gut must be 0, 1 or 2");
         c->adaptive_gut = (int)value;
         return T1D_OK;
     }
@@ -462,6 +466,16 @@ extern "C" int t1d_reset(t1d_ctx* c, const t1d_batch* b, const uint8_t* mask, in
     return T1D_OK;
 }
 
+// more than 64 KiB of dynamic LDS has to be allowed per kernel (once; a context belongs to one device)
+static hipError_t allow_lds(t1d_ctx* c, const void* fn, size_t bytes)
+{
+    if (bytes <= 65536) return hipSuccess;
+    for (const void* f : c->lds_allowed) if (f == fn) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_block - 512);
+    if (e == hipSuccess) c->lds_allowed.push_back(fn);
+    return e;
+}
+
 extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, void* stream)
 {
     int rc = check_batch("t1d_step", c, b, true);
@@ -524,17 +538,31 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             const bool reg = pmode != 0 && !c->adaptive_gut;
             const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
             const bool adapt = c->adaptive_gut != 0;
+            // adaptive scheme: refinement deferred to the end of the launch (step1d_kernel) where the list of the
+            // CU's envs fits next to the tables; adaptive_gut = 2 asks for the in-place form
+            const int per_block = (nchunks + blocks - 1) / blocks;
+            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(int);
+            const bool defer = adapt && c->adaptive_gut == 1 && stride == 32 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(R, TT, ST, EX, AD) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX, AD>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
+#define T1D_LAUNCH_S1D(R, TT, EX) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<R, TT, 32, EX>, dyn1d)); \
+        hipLaunchKernelGGL((step1d_kernel<R, TT, 32, EX>), dim3(blocks), dim3(kS1Threads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
 #define T1D_S1_BY_EXTRA(R, TT, ST) do { if (adapt) { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, true); else T1D_LAUNCH_S1(R, TT, ST, false, true); } \
                                         else { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, false); else T1D_LAUNCH_S1(R, TT, ST, false, false); } } while (0)
-            if (b->dtype == T1D_F64) {
+#define T1D_S1D_BY_EXTRA(R, TT) do { if (extra) T1D_LAUNCH_S1D(R, TT, true); else T1D_LAUNCH_S1D(R, TT, false); } while (0)
+            if (defer) {
+                const bool regd = pmode != 0;              // the main pass has no refinement code: its parameters fit in VGPRs
+                if (b->dtype == T1D_F64) { if (regd) T1D_S1D_BY_EXTRA(true, double); else T1D_S1D_BY_EXTRA(false, double); }
+                else { if (regd) T1D_S1D_BY_EXTRA(true, float); else T1D_S1D_BY_EXTRA(false, float); }
+            } else if (b->dtype == T1D_F64) {
                 if (stride == 32) { if (reg) T1D_S1_BY_EXTRA(true, double, 32); else T1D_S1_BY_EXTRA(false, double, 32); }
                 else { if (reg) T1D_S1_BY_EXTRA(true, double, 64); else T1D_S1_BY_EXTRA(false, double, 64); }
             } else {
                 if (stride == 32) { if (reg) T1D_S1_BY_EXTRA(true, float, 32); else T1D_S1_BY_EXTRA(false, float, 32); }
                 else { if (reg) T1D_S1_BY_EXTRA(true, float, 64); else T1D_S1_BY_EXTRA(false, float, 64); }
             }
+#undef T1D_S1D_BY_EXTRA
 #undef T1D_S1_BY_EXTRA
+#undef T1D_LAUNCH_S1D
 #undef T1D_LAUNCH_S1
             T1D_HIP(hipGetLastError());
             return T1D_OK;

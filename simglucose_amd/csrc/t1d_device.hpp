@@ -390,7 +390,7 @@ __device__ __forceinline__ void rk4_substeps_split(P& p, const MinuteIn<T>& u, T
 //                                 x7 <- [x7, x5, x9, x10, x11, u]
 __host__ __device__ constexpr int kPropRows(int ng) { return 14 * ng + 21; }
 
-struct NoProp { static constexpr bool kSplit = false, kAdapt = false; };
+struct NoProp { static constexpr bool kSplit = false, kAdapt = false, kForce = false; };
 // compact LDS tables with a compile-time row stride (persistent single-minute kernel): every read is one
 // ds_read_b64 with an immediate offset
 template <typename T, int STRIDE> struct ParsLdsS {
@@ -401,14 +401,16 @@ template <typename T, int STRIDE> struct ParsLdsS {
     __device__ __forceinline__ void pin() {}
     __device__ __forceinline__ void pin_split() {}
 };
-template <typename T, int STRIDE, bool ADAPT = false> struct PropLdsS {
-    static constexpr bool kSplit = true, kAdapt = ADAPT;
+// FORCE (with ADAPT): every lane takes the halved gut steps -- the deferred pass of step1d_kernel, whose lanes were
+// all flagged by the same rule beforehand
+template <typename T, int STRIDE, bool ADAPT = false, bool FORCE = false> struct PropLdsS {
+    static constexpr bool kSplit = true, kAdapt = ADAPT, kForce = ADAPT && FORCE;
     const T* base; int pid;
     __device__ __forceinline__ T operator()(int r) const { return base[r * STRIDE + pid]; }
 };
 // table in LDS, [rows][stride] with the patient index fastest (different patients -> different banks)
 template <typename T, bool ADAPT = false> struct PropLds {
-    static constexpr bool kSplit = true, kAdapt = ADAPT;
+    static constexpr bool kSplit = true, kAdapt = ADAPT, kForce = false;
     const T* base; int stride; int pid;
     __device__ __forceinline__ T operator()(int r) const { return base[r * stride + pid]; }
 };
@@ -419,10 +421,40 @@ template <typename T, bool ADAPT = false> struct PropLds {
 // accuracy (steep patients after large meals); it concerns < 1 % of the env-minutes of a RandomScenario day and
 // brings the error against a tight solve down to that of n_sub doubled everywhere.  The second half step runs
 // under the flagged lanes' exec mask and is skipped by waves that have none.
-template <typename T, typename P, typename PR>
-__device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int ng)
+// kgut(x0 + x1) * x1, the flux out of the stomach's liquid compartment                         (t1dpatient.py:126-145)
+template <typename T, typename P>
+__device__ __forceinline__ T kgut_flux(P& p, const MinuteIn<T>& u, T q0, T q1)
+{
+    const T ehi = sizeof(T) == 8 ? T(350) : T(40);     // only overflow needs a guard: exp of a very negative argument is 0
+    const T qsto = q0 + q1;
+    const T a2 = t_min(u.aa * (qsto - u.bD), ehi);
+    const T c2 = t_min(u.cc * (qsto - u.dD), ehi);
+    const T ea = exp_core<10>(a2), ec = exp_core<10>(c2);
+    const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
+    return kgut * q1;
+}
+
+// The refinement rule of the adaptive scheme, from the state at the start of the minute and F1 = kgut_flux there.
+template <typename T>
+__device__ __forceinline__ bool gut_refine_flag(const MinuteIn<T>& u, T g0, T g1, T F1)
+{
+    const T dq = u.d_mg - F1;                                   // d(qsto)/dt at the start of the minute
+    const T q0 = g0 + g1;
+    const T A0 = T(0.5) * u.aa * (q0 - u.bD), dA = T(0.5) * u.aa * dq;      // u.aa, u.cc hold twice the slopes
+    const T C0 = T(0.5) * u.cc * (q0 - u.dD), dC = T(0.5) * u.cc * dq;
+    const T A1 = A0 + dA, C1 = C0 + dC;
+    const bool fa = fabs(dA) > T(4) && (A0 * A1 <= T(0) || t_min(fabs(A0), fabs(A1)) < T(3));
+    const bool fc = fabs(dC) > T(4) && (C0 * C1 <= T(0) || t_min(fabs(C0), fabs(C1)) < T(3));
+    return fa || fc;
+}
+
+// HAVE_F1: the caller has evaluated kgut_flux at the start of the minute already (to take the refinement decision
+// outside) and hands it in as f1_pre.
+template <typename T, typename P, typename PR, bool HAVE_F1 = false>
+__device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int ng, T f1_pre = T(0))
 {
     constexpr bool ADAPT = PR::kAdapt;
+    constexpr bool FORCE = PR::kForce;
     const int ns = ng >> 1;
     const T h = T(1) / T(ng), hh = T(0.5) * h, h6 = h / T(6);
     const T H = h + h, H6 = H / T(6);                 // glucose step; its half step is h
@@ -430,38 +462,21 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
     T g0 = x[0], g1 = x[1], x2 = x[2], R = T(0);      // R: mass that left x2 through kabs since the minute began
     T z3 = x[3], x4 = x[4], x12 = x[12];
     T cRa = T(0), cDa = p(DP_RATC) * x2, x6a = s6, x8a = s8;      // c R, c R', X, XL at the start of the glucose step
-    const T ehi = sizeof(T) == 8 ? T(350) : T(40);     // only overflow needs a guard: exp of a very negative argument is 0
-
-    auto kgutF = [&](T q0, T q1) -> T {                // kgut(x0 + x1) * x1                       (:126-145)
-        const T qsto = q0 + q1;
-        const T a2 = t_min(u.aa * (qsto - u.bD), ehi);
-        const T c2 = t_min(u.cc * (qsto - u.dD), ehi);
-        const T ea = exp_core<10>(a2), ec = exp_core<10>(c2);
-        const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
-        return kgut * q1;
-    };
+    auto kgutF = [&](T q0, T q1) -> T { return kgut_flux(p, u, q0, q1); };
     // One RK4 step of (x0, x1) + the exponential update of x2.  `pre(k)` / `post(k)` run before / after stage k's
     // gastric-emptying evaluation: the caller issues the LDS reads of a propagator row in pre() and consumes them
     // in post(), so that their latency hides behind ~50 dependent VALU instructions instead of being waited out.
     // per-lane gut step and x2 weights (ADAPT: halved in flagged minutes; the flag is known after the first stage
     // of the minute, whose value F1 = kgut x1 at the start does not depend on the step)
-    bool refine = false;
+    bool refine = FORCE;
     auto gut_step = [&](auto&& pre, auto&& post, bool first_of_minute) {
         p.refresh();
         const T kmax = p(DP_KMAX);
         pre(0);
-        const T F1 = kgutF(g0, g1);
+        T F1;
+        if (HAVE_F1 && first_of_minute) F1 = f1_pre; else F1 = kgutF(g0, g1);
         post(0, F1);
-        if (ADAPT && first_of_minute) {
-            const T dq = u.d_mg - F1;                                   // d(qsto)/dt at the start of the minute
-            const T q0 = g0 + g1;
-            const T A0 = T(0.5) * u.aa * (q0 - u.bD), dA = T(0.5) * u.aa * dq;      // u.aa, u.cc hold twice the slopes
-            const T C0 = T(0.5) * u.cc * (q0 - u.dD), dC = T(0.5) * u.cc * dq;
-            const T A1 = A0 + dA, C1 = C0 + dC;
-            const bool fa = fabs(dA) > T(4) && (A0 * A1 <= T(0) || t_min(fabs(A0), fabs(A1)) < T(3));
-            const bool fc = fabs(dC) > T(4) && (C0 * C1 <= T(0) || t_min(fabs(C0), fabs(C1)) < T(3));
-            refine = fa || fc;
-        }
+        if (ADAPT && !FORCE && first_of_minute) refine = gut_refine_flag(u, g0, g1, F1);
         const T sc = (ADAPT && refine) ? T(0.5) : T(1);                 // exact scalings: the step sizes are not kept in registers
         const T gh = sc * h, ghh = sc * hh, gh6 = sc * h6;
         const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;

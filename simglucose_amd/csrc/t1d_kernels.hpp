@@ -485,6 +485,165 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
 constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a CU: T1D_S1_WAVES waves on each of its 4 SIMDs
 // EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
 // third risk evaluation drop out of the kernel altogether
+//
+// One env-minute of one lane: everything between the chunk's loads and its last store.  MODE:
+//   0  fixed gut steps;
+//   1  adaptive, in place: flagged lanes take their halved gut steps under their exec mask (split_minute);
+//   2  main pass of step1d_kernel: fixed steps; the refinement flag is evaluated right after the meal bookkeeping
+//      and handed to on_flag(flag) -- a flagged lane stops there, before anything is stored;
+//   3  deferred pass of step1d_kernel: every lane was flagged, every lane takes the halved steps.
+template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONFLAG>
+__device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, ONFLAG&& on_flag,
+                                         long long* tr, int tk)
+{
+    constexpr bool ADAPT = MODE == 1 || MODE == 3;
+    (void)tr; (void)tk;
+    S1_MARK(0);
+    const uint32_t meta = at(row(a.t, a.n, 1), i);
+    const uint32_t pid = T1D_META_PID(meta);
+    Env<T> e;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
+    e.planned = at(row(a.x, a.n, 13), i); e.lq = at(row(a.x, a.n, 14), i); e.lf = at(row(a.x, a.n, 15), i);
+    const T planned0 = e.planned, lq0 = e.lq, lf0 = e.lf;
+    e.t = at(a.t, i);
+    e.next_meal = at(row(a.t, a.n, 2), i);
+    e.next_meal_loaded = e.next_meal;
+    e.eating = (meta & T1D_META_EATING) != 0;
+    e.cursor = (int)T1D_META_CURSOR(meta);
+    const T basal = at(a.basal, i);
+    const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+    S1_MARK(1);
+    T q_basal, q_bolus;
+    if (a.flags & T1D_BATCH_NO_PUMP) {
+        q_basal = basal; q_bolus = a.bolus ? bolus : T(0);
+    } else {
+        int z = 0;
+        asm volatile("" : "+v"(z));                  // opaque index: the reads below stay inside the chunk loop
+        const T* lc = lconst + z;
+        q_basal = pump_quantise(basal, lc[0], lc[1], lc[2]);                                   // env.py:51
+        q_bolus = lc[4] > T(0) ? lc[4] : T(0);
+        if (a.bolus) q_bolus = pump_quantise(bolus, lc[3], lc[4], lc[5]);                      // env.py:52
+    }
+    const T insulin = q_basal + q_bolus;
+    const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
+    ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
+    MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+    T f1 = T(0);
+    if (MODE == 2) {
+        f1 = kgut_flux(pl, u, e.x[0], e.x[1]);
+        const bool flag = gut_refine_flag(u, e.x[0], e.x[1], f1);
+        on_flag(flag);
+        if (flag) return;                            // nothing stored: the deferred pass redoes this lane from its loads
+    }
+    // bookkeeping is final for this minute: store it now -- the meal words only where they changed (they do
+    // while an env is eating, ~3 % of the minutes: 24 B per env-step of write traffic otherwise)
+    if (e.planned != planned0) at(row(a.x, a.n, 13), i) = e.planned;
+    if (e.lq != lq0) at(row(a.x, a.n, 14), i) = e.lq;
+    if (e.lf != lf0) at(row(a.x, a.n, 15), i) = e.lf;
+    at(a.t, i) = e.t + 1;
+    if (e.next_meal != e.next_meal_loaded) at(row(a.t, a.n, 2), i) = e.next_meal;
+    {   // patient id, eating flag, meal cursor: changes when a meal starts, ends or fires
+        const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+        if (meta1 != meta) at(row(a.t, a.n, 1), i) = meta1;
+    }
+    if (EXTRA) {
+        if (a.meal) at(a.meal, i) = meal;
+        if (a.insulin) at(a.insulin, i) = insulin;
+    }
+    S1_MARK(2);
+    {
+        PropLdsS<T, STRIDE, ADAPT, MODE == 3> pr{lpr, (int)pid};
+        if (REG) {
+            ParsReg<T> p;
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
+            if (ADAPT) {
+#pragma unroll
+                for (int k = 0; k < (int)(sizeof(kAdaptPars) / sizeof(int)); ++k) p.v[kAdaptPars[k]] = pl(kAdaptPars[k]);
+            }
+            p.pin_split();
+            if (!(a.flags & 0x800)) split_minute<T, ParsReg<T>, decltype(pr), MODE == 2>(p, pr, u, e.x, a.n_sub, f1);
+        } else {
+            if (!(a.flags & 0x800)) split_minute<T, ParsLdsS<T, STRIDE>, decltype(pr), MODE == 2>(pl, pr, u, e.x, a.n_sub, f1);
+        }
+    }
+    S1_MARK(3);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
+    // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.x, a.n, 40 + k), i);
+    // with a 1-minute sensor every minute takes a fresh sample: the held value is never read
+    T last_cgm = a.sen.st == 1 ? T(0) : (T)at(row(a.x, a.n, 16), i);
+    const T prev_cgm = at(row(a.x, a.n, 17), i);
+    S1_MARK(4);
+    bool due;
+    const T noise = measure_noise<false>(a, i, e, due);       // e.t is still the minute's start: sample for t + 1
+    const T rp = prev_risk<1>(a, prev_cgm);
+    const T gsub = e.x[12] * pl(DP_IVG);                                                       // t1dpatient.py:217-218
+    if (due) {                                                                                 // cgm.py:26-36
+        T c = gsub + noise;
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        const T vmin = lconst[6 + z], vmax = lconst[7 + z];
+        c = c > vmin ? c : vmin;
+        c = c < vmax ? c : vmax;
+        last_cgm = c;
+        if (a.sen.st != 1) at(row(a.x, a.n, 16), i) = c;      // the zero-order hold is dead state with a 1-minute sensor
+    }
+    T l, h, r, rc = T(0);
+    if (!(a.flags & 0x100)) risk_index1<1>(last_cgm, l, h, rc);
+    at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
+    at(row(a.x, a.n, 17), i) = last_cgm;
+    at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
+    at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
+    if (EXTRA && (a.lbgi || a.hbgi || a.risk)) {
+        risk_index1<1>(gsub, l, h, r);                                                         // env.py:85
+        if (a.lbgi) at(a.lbgi, i) = l;
+        if (a.hbgi) at(a.hbgi, i) = h;
+        if (a.risk) at(a.risk, i) = r;
+    }
+    if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+#if T1D_S1_TRACE
+    if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + 5] = (long long)wall_clock64();    // epilogue computed, stores issued
+#endif
+    S1_MARK(6);
+}
+
+struct S1NoFlag { __device__ __forceinline__ void operator()(bool) const {} };
+
+// tables of one CU, staged once per launch; returns nothing: ldp = [DP_COUNT][STRIDE], lpr = [prop_rows][STRIDE]
+template <typename T, int STRIDE>
+__device__ __forceinline__ void s1_stage_tables(const KArgs<T>& a, T* ldp, T* lpr, T* lconst)
+{
+    for (int j = threadIdx.x; j < DP_COUNT * STRIDE; j += kS1Threads) {
+        const int r = j / STRIDE, c = j % STRIDE;
+        ldp[j] = c < a.np ? a.dpar[r * kMaxPatients + c] : T(0);
+    }
+    for (int j = threadIdx.x; j < a.prop_rows * STRIDE; j += kS1Threads) {
+        const int r = j / STRIDE, c = j % STRIDE;
+        lpr[j] = c < a.np ? a.prop[r * a.np_pad + c] : T(0);
+    }
+    if (threadIdx.x == 0) {
+        lconst[0] = a.pump.inc_basal; lconst[1] = a.pump.min_basal; lconst[2] = a.pump.max_basal;
+        lconst[3] = a.pump.inc_bolus; lconst[4] = a.pump.min_bolus; lconst[5] = a.pump.max_bolus;
+        lconst[6] = a.sen.vmin; lconst[7] = a.sen.vmax;
+    }
+}
+
+// rotate the issue priority among the waves of a SIMD (waves w, w + 4, w + 8 of the workgroup) chunk by chunk
+__device__ __forceinline__ void s1_rotate_prio(int it)
+{
+#if T1D_S1_ROTATE_PRIO
+    switch ((unsigned)(it + (int)(threadIdx.x >> 8)) % 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(2); break;
+    }
+#endif
+}
+
 template <bool REG, typename T, int STRIDE, bool EXTRA, bool ADAPT>
 __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
@@ -496,20 +655,8 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
     __shared__ int queue;
     __shared__ T lconst[8];                              // pump and sensor limits: read from LDS where used, so that they
                                                          // do not sit in (spilled) scalar registers across the whole kernel
-    for (int j = threadIdx.x; j < DP_COUNT * STRIDE; j += kS1Threads) {
-        const int r = j / STRIDE, c = j % STRIDE;
-        ldp[j] = c < a.np ? a.dpar[r * kMaxPatients + c] : T(0);
-    }
-    for (int j = threadIdx.x; j < a.prop_rows * STRIDE; j += kS1Threads) {
-        const int r = j / STRIDE, c = j % STRIDE;
-        lpr[j] = c < a.np ? a.prop[r * a.np_pad + c] : T(0);
-    }
-    if (threadIdx.x == 0) {
-        queue = 0;
-        lconst[0] = a.pump.inc_basal; lconst[1] = a.pump.min_basal; lconst[2] = a.pump.max_basal;
-        lconst[3] = a.pump.inc_bolus; lconst[4] = a.pump.min_bolus; lconst[5] = a.pump.max_bolus;
-        lconst[6] = a.sen.vmin; lconst[7] = a.sen.vmax;
-    }
+    s1_stage_tables<T, STRIDE>(a, ldp, lpr, lconst);
+    if (threadIdx.x == 0) queue = 0;
     __syncthreads();
     // This workgroup owns a contiguous run of 64-env chunks; its waves draw them from a queue in LDS.  The
     // SIMD issues oldest-wave-first, so with a fixed share per wave the first wave of a SIMD would race ahead
@@ -520,8 +667,10 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
     const unsigned lane = threadIdx.x & 63u;
 #if T1D_S1_TRACE
     long long* tr = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (kS1Threads / 64) + threadIdx.x / 64) * 64 : nullptr;
-    int tk = -1;
+#else
+    long long* tr = nullptr;
 #endif
+    int tk = -1;
     for (int it = 0;; ++it) {
         int c = 0;
         if (lane == 0) c = atomicAdd(&queue, 1);
@@ -530,121 +679,70 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         const unsigned i = (unsigned)(first + c) * 64u + lane;
         __builtin_assume(i < (1u << 28));
         if ((int64_t)i >= a.n) continue;
-#if T1D_S1_TRACE
         ++tk;
-#endif
-#if T1D_S1_ROTATE_PRIO
-        // rotate the issue priority among the waves of a SIMD (waves w, w + 4, w + 8 of the workgroup) chunk by chunk
-        switch ((unsigned)(it + (int)(threadIdx.x >> 8)) % 3u) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            default: __builtin_amdgcn_s_setprio(2); break;
+        s1_rotate_prio(it);
+        s1_chunk<REG, T, STRIDE, EXTRA, ADAPT ? 1 : 0>(a, ldp, lpr, lconst, i, S1NoFlag(), tr, tk);
+    }
+}
+
+// step1_kernel with the adaptive scheme's refinement DEFERRED.  In place (MODE 1 above) a wave with one flagged lane
+// runs the four extra half steps of the minute for that one lane: 0.7 % of the env-minutes of random-meal days are
+// flagged, but 37 % of the waves hold at least one, and the launch pays +17 %.  Here the main pass integrates with
+// fixed steps and a flagged lane only leaves its env index in a list in LDS (before anything of it is stored);
+// waves that find the chunk queue empty wait until every chunk of the CU is past that point and then take the
+// listed envs 64 at a time, all lanes refining.  The list holds every env of the CU's share (t1d_step sizes it),
+// so it cannot overflow; the per-lane arithmetic is that of MODE 1, lane for lane.
+template <bool REG, typename T, int STRIDE, bool EXTRA>
+__global__ __launch_bounds__(kS1Threads, 1) void step1d_kernel(const KArgs<T> a, int nchunks)
+{
+    T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
+    T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
+    int* const dlist = (int*)(lpr + a.prop_rows * STRIDE); // [per_block * 64] env indices awaiting refinement
+    __shared__ int queue, queue2, dcount, passed;
+    __shared__ T lconst[8];
+    s1_stage_tables<T, STRIDE>(a, ldp, lpr, lconst);
+    if (threadIdx.x == 0) { queue = 0; queue2 = 0; dcount = 0; passed = 0; }
+    __syncthreads();
+    const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int first = (int)blockIdx.x * per_block;
+    const int count = nchunks - first < per_block ? nchunks - first : per_block;
+    const unsigned lane = threadIdx.x & 63u;
+    long long* tr = nullptr;
+    int it = 0;
+    for (;; ++it) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&queue, 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= count) break;                              // wave-uniform
+        const unsigned i = (unsigned)(first + c) * 64u + lane;
+        __builtin_assume(i < (1u << 28));
+        s1_rotate_prio(it);
+        if ((int64_t)i < a.n) {
+            s1_chunk<REG, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, [&](bool flag) {
+                if (flag) dlist[atomicAdd(&dcount, 1)] = (int)i;
+                // lane 0 of a chunk is always a live env: it reports the chunk past its flag point, after the
+                // list entries of the wave (LDS operations of one wave execute in order)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicAdd(&passed, 1);
+            }, tr, 0);
         }
-#endif
-        S1_MARK(0);
-        const uint32_t meta = at(row(a.t, a.n, 1), i);
-        const uint32_t pid = T1D_META_PID(meta);
-        Env<T> e;
-#pragma unroll
-        for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
-        e.planned = at(row(a.x, a.n, 13), i); e.lq = at(row(a.x, a.n, 14), i); e.lf = at(row(a.x, a.n, 15), i);
-        const T planned0 = e.planned, lq0 = e.lq, lf0 = e.lf;
-        e.t = at(a.t, i);
-        e.next_meal = at(row(a.t, a.n, 2), i);
-        e.next_meal_loaded = e.next_meal;
-        e.eating = (meta & T1D_META_EATING) != 0;
-        e.cursor = (int)T1D_META_CURSOR(meta);
-        const T basal = at(a.basal, i);
-        const T bolus = a.bolus ? at(a.bolus, i) : T(0);
-        S1_MARK(1);
-        T q_basal, q_bolus;
-        if (a.flags & T1D_BATCH_NO_PUMP) {
-            q_basal = basal; q_bolus = a.bolus ? bolus : T(0);
-        } else {
-            int z = 0;
-            asm volatile("" : "+v"(z));                  // opaque index: the reads below stay inside the chunk loop
-            const T* lc = lconst + z;
-            q_basal = pump_quantise(basal, lc[0], lc[1], lc[2]);                                   // env.py:51
-            q_bolus = lc[4] > T(0) ? lc[4] : T(0);
-            if (a.bolus) q_bolus = pump_quantise(bolus, lc[3], lc[4], lc[5]);                      // env.py:52
+    }
+    // every chunk of this CU has been drawn; those still in flight may yet add to the list
+    while (__hip_atomic_load(&passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < count) __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int total = __hip_atomic_load(&dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;; ++it) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&queue2, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g * 64 >= total) break;                         // wave-uniform
+        const int idx = g * 64 + (int)lane;
+        s1_rotate_prio(it);
+        if (idx < total) {
+            const unsigned i = (unsigned)dlist[idx];
+            __builtin_assume(i < (1u << 28));
+            s1_chunk<false, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoFlag(), tr, 0);
         }
-        const T insulin = q_basal + q_bolus;
-        const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
-        ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
-        MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
-        // bookkeeping is final for this minute: store it now -- the meal words only where they changed (they do
-        // while an env is eating, ~3 % of the minutes: 24 B per env-step of write traffic otherwise)
-        if (e.planned != planned0) at(row(a.x, a.n, 13), i) = e.planned;
-        if (e.lq != lq0) at(row(a.x, a.n, 14), i) = e.lq;
-        if (e.lf != lf0) at(row(a.x, a.n, 15), i) = e.lf;
-        at(a.t, i) = e.t + 1;
-        if (e.next_meal != e.next_meal_loaded) at(row(a.t, a.n, 2), i) = e.next_meal;
-        {   // patient id, eating flag, meal cursor: changes when a meal starts, ends or fires
-            const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
-            if (meta1 != meta) at(row(a.t, a.n, 1), i) = meta1;
-        }
-        if (EXTRA) {
-            if (a.meal) at(a.meal, i) = meal;
-            if (a.insulin) at(a.insulin, i) = insulin;
-        }
-        S1_MARK(2);
-        {
-            PropLdsS<T, STRIDE, ADAPT> pr{lpr, (int)pid};
-            if (REG) {
-                ParsReg<T> p;
-#pragma unroll
-                for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
-                if (ADAPT) {
-#pragma unroll
-                    for (int k = 0; k < (int)(sizeof(kAdaptPars) / sizeof(int)); ++k) p.v[kAdaptPars[k]] = pl(kAdaptPars[k]);
-                }
-                p.pin_split();
-                if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub);
-            } else {
-                if (!(a.flags & 0x800)) split_minute(pl, pr, u, e.x, a.n_sub);
-            }
-        }
-        S1_MARK(3);
-#pragma unroll
-        for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
-        // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.x, a.n, 40 + k), i);
-        // with a 1-minute sensor every minute takes a fresh sample: the held value is never read
-        T last_cgm = a.sen.st == 1 ? T(0) : (T)at(row(a.x, a.n, 16), i);
-        const T prev_cgm = at(row(a.x, a.n, 17), i);
-        S1_MARK(4);
-        bool due;
-        const T noise = measure_noise<false>(a, i, e, due);       // e.t is still the minute's start: sample for t + 1
-        const T rp = prev_risk<1>(a, prev_cgm);
-        const T gsub = e.x[12] * pl(DP_IVG);                                                       // t1dpatient.py:217-218
-        if (due) {                                                                                 // cgm.py:26-36
-            T c = gsub + noise;
-            int z = 0;
-            asm volatile("" : "+v"(z));
-            const T vmin = lconst[6 + z], vmax = lconst[7 + z];
-            c = c > vmin ? c : vmin;
-            c = c < vmax ? c : vmax;
-            last_cgm = c;
-            if (a.sen.st != 1) at(row(a.x, a.n, 16), i) = c;      // the zero-order hold is dead state with a 1-minute sensor
-        }
-        T l, h, r, rc = T(0);
-        if (!(a.flags & 0x100)) risk_index1<1>(last_cgm, l, h, rc);
-        at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
-        at(row(a.x, a.n, 17), i) = last_cgm;
-        at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
-        at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
-        if (EXTRA && (a.lbgi || a.hbgi || a.risk)) {
-            risk_index1<1>(gsub, l, h, r);                                                         // env.py:85
-            if (a.lbgi) at(a.lbgi, i) = l;
-            if (a.hbgi) at(a.hbgi, i) = h;
-            if (a.risk) at(a.risk, i) = r;
-        }
-        if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
-#if T1D_S1_TRACE
-        if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + 5] = (long long)wall_clock64();    // epilogue computed, stores issued
-#endif
-        S1_MARK(6);
     }
 }
 

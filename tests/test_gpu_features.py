@@ -534,6 +534,46 @@ def test_fp32_single_minute_kernel_tracks_fp64():
     assert envs[0].sync() == 0 and envs[1].sync() == 0
 
 
+@pytest.mark.parametrize("dtype_name", ["f64", "f32"])
+def test_deferred_refinement_equals_in_place_refinement(dtype_name):
+    """The single-minute kernel with the adaptive scheme's refinement deferred to the end of the launch (default,
+    step1d_kernel) against the in-place form (adaptive_gut = 2): the same lanes refine and take the same arithmetic,
+    so the states agree to rounding (different instantiations may contract FMAs differently) -- 8 h with meals, with
+    the default grid and with a 3-block grid (many chunks per wave, a long list per block), extra outputs on and off.
+    Some envs share their meal times so that whole waves are flagged at once."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    dt = torch.float64 if dtype_name == "f64" else torch.float32
+    n = 64 * 200 - 7                              # the last chunk is partly masked
+    pid = np.arange(n) % 30
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=6 * 60, seed=11, device="cuda:0", dtype=dt)
+    mt[:, :640] = mt[:, :1]; ma[:, :640] = ma[:, :1]        # ten waves of envs with one meal plan
+    for extra, blocks in ((False, 0), (True, 3)):
+        envs = []
+        for form in (2, 1):
+            e = _mk(patient=pid, sensor="Navigator", dtype=dt, noise="philox", seed=4, n_sub=4, extra_outputs=extra)
+            e.set_option("adaptive_gut", form)
+            e.set_option("pipe_blocks", blocks)
+            e.set_meals(mt, ma)
+            e.reset()
+            envs.append(e)
+        b = torch.as_tensor(_basal(pid), device="cuda:0", dtype=dt)
+        tol = 1e-9 if dtype_name == "f64" else 2e-3
+        for k in range(480 if not extra else 150):
+            a = b * (0.5 + 0.25 * (k % 7))
+            envs[0].step(a); envs[1].step(a)
+            if k % 30 == 29:
+                assert float((envs[0].bg - envs[1].bg).abs().max()) < tol, k
+        assert torch.equal(envs[0].t, envs[1].t) and torch.equal(envs[0].done, envs[1].done)
+        assert float((envs[0].x - envs[1].x).abs().max()) < tol * 100
+        assert float((envs[0].cgm - envs[1].cgm).abs().max()) < tol
+        assert float((envs[0].reward - envs[1].reward).abs().max()) < tol
+        if extra:
+            assert float((envs[0].risk - envs[1].risk).abs().max()) < tol
+            assert torch.equal(envs[0].meal, envs[1].meal)
+        assert envs[0].sync() == 0 and envs[1].sync() == 0
+
+
 def test_state_dict_roundtrip_and_determinism():
     import torch
     n = 512

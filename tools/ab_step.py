@@ -20,10 +20,12 @@ from simglucose_amd.batch_env import BatchedT1DSimEnv  # noqa: E402
 from simglucose_amd import params, scenario_batch  # noqa: E402
 
 
-def make(n, layout, dt, sensor, n_sub):
+def make(n, layout, dt, sensor, n_sub, start="random"):
     pid = (np.arange(n) % 30) if layout == "mod30" else ((np.arange(n) // 64) % 30)
     env = BatchedT1DSimEnv(patient=pid, sensor=sensor, dtype=dt, n_sub=n_sub, seed=5, extra_outputs=False)
-    mt, ma = scenario_batch.random_meal_tables(n, days=2, seed=3, device=env.device, dtype=dt)
+    g0 = torch.Generator(device=env.device); g0.manual_seed(11)
+    start_min = torch.randint(0, 1440, (n,), generator=g0, device=env.device, dtype=torch.int32) if start == "random" else 0
+    mt, ma = scenario_batch.random_meal_tables(n, days=2, start_minute_of_day=start_min, seed=3, device=env.device, dtype=dt)
     env.set_meals(mt, ma)
     names, tab = params.patient_table()
     b0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, dtype=dt, device=env.device)
@@ -42,11 +44,13 @@ def main():
     ap.add_argument("--sensor", default="Navigator")
     ap.add_argument("--n-sub", type=int, default=4)
     ap.add_argument("--variants", default="reg,g_split_reg,split_lds,split_reg")
+    ap.add_argument("--start", choices=("random", "midnight"), default="random",
+                    help="episode start: a random minute of the day per env (every launch sees the day's mix of meal phases) or 00:00 for all")
     a = ap.parse_args()
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     cfgs = []
     for layout in ("mod30", "run64"):
-        env, pool = make(a.envs, layout, dt, a.sensor, a.n_sub)
+        env, pool = make(a.envs, layout, dt, a.sensor, a.n_sub, a.start)
         for var in a.variants.split(","):
             if var in ("scalar", "pipe_scalar") and not env.wave_uniform:
                 continue
@@ -58,7 +62,7 @@ def main():
             env.set_option("scalar_params", 1 if var in ("scalar", "pipe_scalar") else 0)
             env.set_option("params_mode", 1 if var.endswith("reg") else 0)
             env.set_option("integrator", 1 if "split" in var else 0)
-            env.set_option("adaptive_gut", 1 if "adapt" in var else 0)
+            env.set_option("adaptive_gut", (2 if "inplace" in var else 1) if "adapt" in var else 0)   # adapt: deferred refinement where it fits; adapt_inplace: masked half steps in place
             env.set_option("single_minute_kernel", 0 if var.startswith("g_") else 1)      # g_: generic one-tile-per-block kernel
             env.set_option("pipeline", 1 if var.startswith("pipe") else 0)
             for k in range(3):

@@ -1,0 +1,7 @@
+#!/bin/bash
+# deferred against in-place refinement of the single-minute kernel over batch sizes (GPU box)
+mkdir -p gpurun_out
+for n in 16384 65536 131072 262144 524288 2097152; do
+  echo "== envs $n"
+  timeout -k 10 120 python tools/ab_step.py --envs $n --variants split_adapt_reg,split_adapt_inplace_lds --rounds 3 --steps 100 2>&1 | grep "^mod30"
+done
