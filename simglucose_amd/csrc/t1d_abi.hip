@@ -367,7 +367,7 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         return T1D_OK;
     }
     if (std::strcmp(name, "adaptive_gut") == 0) {
-        if (value < 0 || value > 2) return fail(T1D_E_INVALID, "t1d_ctx_set_option: adaptive_gut must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(T1D_E_INVALID, "t1d_ctx_set_option: adaptive_gut must be 0, 1, 2 or 3");
         c->adaptive_gut = (int)value;
         return T1D_OK;
     }
@@ -542,7 +542,10 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             // CU's envs fits next to the tables; adaptive_gut = 2 asks for the in-place form
             const int per_block = (nchunks + blocks - 1) / blocks;
             const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(int);
-            const bool defer = adapt && c->adaptive_gut == 1 && stride == 32 && dyn1d + 512 <= (size_t)c->lds_per_block;
+            // (below ~8 chunks per CU the launch is latency-bound and the deferred pass is a second chunk in series:
+            // 65 536 envs 21 vs 17 us, 131 072 envs 26 vs 27 us, 1 Mi envs 93 vs 111 us)
+            const bool defer = adapt && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= 8)) && stride == 32 &&
+                               dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(R, TT, ST, EX, AD) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX, AD>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
 #define T1D_LAUNCH_S1D(R, TT, EX) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<R, TT, 32, EX>, dyn1d)); \
         hipLaunchKernelGGL((step1d_kernel<R, TT, 32, EX>), dim3(blocks), dim3(kS1Threads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)

@@ -550,7 +550,7 @@ def test_deferred_refinement_equals_in_place_refinement(dtype_name):
     mt[:, :640] = mt[:, :1]; ma[:, :640] = ma[:, :1]        # ten waves of envs with one meal plan
     for extra, blocks in ((False, 0), (True, 3)):
         envs = []
-        for form in (2, 1):
+        for form in (2, 3):                       # 3: deferred whatever the batch size (1 = only from 8 chunks per CU)
             e = _mk(patient=pid, sensor="Navigator", dtype=dt, noise="philox", seed=4, n_sub=4, extra_outputs=extra)
             e.set_option("adaptive_gut", form)
             e.set_option("pipe_blocks", blocks)

@@ -62,7 +62,7 @@ def main():
             env.set_option("scalar_params", 1 if var in ("scalar", "pipe_scalar") else 0)
             env.set_option("params_mode", 1 if var.endswith("reg") else 0)
             env.set_option("integrator", 1 if "split" in var else 0)
-            env.set_option("adaptive_gut", (2 if "inplace" in var else 1) if "adapt" in var else 0)   # adapt: deferred refinement where it fits; adapt_inplace: masked half steps in place
+            env.set_option("adaptive_gut", (2 if "inplace" in var else 3 if "defer" in var else 1) if "adapt" in var else 0)   # adapt: the library's choice; adapt_defer: deferred refinement wherever it fits; adapt_inplace: masked half steps in place
             env.set_option("single_minute_kernel", 0 if var.startswith("g_") else 1)      # g_: generic one-tile-per-block kernel
             env.set_option("pipeline", 1 if var.startswith("pipe") else 0)
             for k in range(3):

@@ -11,7 +11,10 @@ from simglucose_amd import params, scenario_batch  # noqa: E402
 def make(n, dt, sensor, n_sub=4, days=8):
     pid = np.arange(n) % 30
     env = BatchedT1DSimEnv(patient=pid, sensor=sensor, dtype=dt, n_sub=n_sub, seed=5, extra_outputs=False)
-    mt, ma = scenario_batch.random_meal_tables(n, days=days, seed=3, device=env.device, dtype=dt)
+    # episodes start at a random minute of the day per env: every launch sees the day's mix of meal phases
+    g0 = torch.Generator(device=env.device); g0.manual_seed(11)
+    start_min = torch.randint(0, 1440, (n,), generator=g0, device=env.device, dtype=torch.int32)
+    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=start_min, seed=3, device=env.device, dtype=dt)
     env.set_meals(mt, ma)
     _, tab = params.patient_table()
     b0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, dtype=dt, device=env.device)
