@@ -543,7 +543,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             const int per_block = (nchunks + blocks - 1) / blocks;
             const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(int);
             // (below ~8 chunks per CU the launch is latency-bound and the deferred pass is a second chunk in series:
-            // 65 536 envs 21 vs 17 us, 131 072 envs 26 vs 27 us, 1 Mi envs 93 vs 111 us)
+            // 16 384 envs 16.1 vs 15.1 us, 65 536 envs 16.7 vs 16.4 us, 131 072 envs 22 vs 27 us, 1 Mi envs 92 vs 111 us)
             const bool defer = adapt && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= 8)) && stride == 32 &&
                                dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(R, TT, ST, EX, AD) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX, AD>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)

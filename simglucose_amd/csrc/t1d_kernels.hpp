@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1d_kernel(const KArgs<T> a,
         g = __builtin_amdgcn_readfirstlane(g);
         if (g * 64 >= total) break;                         // wave-uniform
         const int idx = g * 64 + (int)lane;
-        s1_rotate_prio(it);
+        __builtin_amdgcn_s_setprio(3);                      // the launch ends with this pass: it goes first on its SIMD
         if (idx < total) {
             const unsigned i = (unsigned)dlist[idx];
             __builtin_assume(i < (1u << 28));
