@@ -145,6 +145,20 @@ __device__ __forceinline__ double exp_core(double v)
     const double n = rint(v * 1.4426950408889634074);
     double r = fma(-n, kc<LOCAL>(6.93147180369123816490e-01), v);
     r = fma(-n, kc<LOCAL>(1.90821492927058770002e-10), r);
+    if (DEG == 8) {
+        // degree 8 with the two leading coefficients exactly 1, the rest fitted to the relative error on |r| <= ln2/2
+        // (1.2e-12; the degree-10 Taylor form below has 3e-13): what the gastric-emptying term gets, 32 times a minute
+        double q = 2.4708212316486418e-05;
+        q = fma(q, r, kc<LOCAL>(1.990893403424476e-04));
+        q = fma(q, r, kc<LOCAL>(1.3889197248979142e-03));
+        q = fma(q, r, kc<LOCAL>(8.333281816073849e-03));
+        q = fma(q, r, kc<LOCAL>(4.166666440468533e-02));
+        q = fma(q, r, kc<LOCAL>(1.6666666784412462e-01));
+        q = fma(q, r, kc<LOCAL>(5.000000000426794e-01));
+        q = fma(q, r, 1.0);
+        q = fma(q, r, 1.0);
+        return ldexp(q, (int)n);
+    }
     double p;
     if (DEG >= 12) {
         p = 2.08767569878680989792e-09;                // 1/12!
@@ -429,7 +443,7 @@ __device__ __forceinline__ T kgut_flux(P& p, const MinuteIn<T>& u, T q0, T q1)
     const T qsto = q0 + q1;
     const T a2 = t_min(u.aa * (qsto - u.bD), ehi);
     const T c2 = t_min(u.cc * (qsto - u.dD), ehi);
-    const T ea = exp_core<10>(a2), ec = exp_core<10>(c2);
+    const T ea = exp_core<8>(a2), ec = exp_core<8>(c2);
     const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
     return kgut * q1;
 }
