@@ -103,6 +103,7 @@ template <typename T> struct MinuteIn {
     T ins;       // insulin, pmol/kg/min                   (:122)
     T aa, cc;    // tanh slopes (MATH 0) or twice them (MATH 1)   (:136-137)
     T bD, dD;    // b*Dbar, d*Dbar                         (:139-140)
+    T aabD, ccdD;   // aa*bD, cc*dD (MATH 1): the tanh arguments are then one FMA each, aa*qsto - aabD
     bool has_dbar;
 };
 
@@ -143,9 +144,9 @@ template <int DEG = 12, bool LOCAL = false>
 __device__ __forceinline__ double exp_core(double v)
 {
     const double n = rint(v * 1.4426950408889634074);
-    double r = fma(-n, kc<LOCAL>(6.93147180369123816490e-01), v);
-    r = fma(-n, kc<LOCAL>(1.90821492927058770002e-10), r);
     if (DEG == 8) {
+        // one-constant range reduction: |n| (ln2 - fl(ln2)) = |n| 2.3e-17, far below the polynomial's 1.2e-12
+        const double r = fma(-n, kc<LOCAL>(6.93147180559945309417e-01), v);
         // degree 8 with the two leading coefficients exactly 1, the rest fitted to the relative error on |r| <= ln2/2
         // (1.2e-12; the degree-10 Taylor form below has 3e-13): what the gastric-emptying term gets, 32 times a minute
         double q = 2.4708212316486418e-05;
@@ -159,6 +160,8 @@ __device__ __forceinline__ double exp_core(double v)
         q = fma(q, r, 1.0);
         return ldexp(q, (int)n);
     }
+    double r = fma(-n, kc<LOCAL>(6.93147180369123816490e-01), v);
+    r = fma(-n, kc<LOCAL>(1.90821492927058770002e-10), r);
     double p;
     if (DEG >= 12) {
         p = 2.08767569878680989792e-09;                // 1/12!
@@ -441,8 +444,9 @@ __device__ __forceinline__ T kgut_flux(P& p, const MinuteIn<T>& u, T q0, T q1)
 {
     const T ehi = sizeof(T) == 8 ? T(350) : T(40);     // only overflow needs a guard: exp of a very negative argument is 0
     const T qsto = q0 + q1;
-    const T a2 = t_min(u.aa * (qsto - u.bD), ehi);
-    const T c2 = t_min(u.cc * (qsto - u.dD), ehi);
+    // fp64: one FMA per argument (the cancellation costs ~3e-14 absolute); fp32 keeps the difference form
+    const T a2 = t_min(sizeof(T) == 8 ? (T)fma((double)u.aa, (double)qsto, -(double)u.aabD) : u.aa * (qsto - u.bD), ehi);
+    const T c2 = t_min(sizeof(T) == 8 ? (T)fma((double)u.cc, (double)qsto, -(double)u.ccdD) : u.cc * (qsto - u.dD), ehi);
     const T ea = exp_core<8>(a2), ec = exp_core<8>(c2);
     const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
     return kgut * q1;
@@ -663,6 +667,8 @@ __device__ __forceinline__ MinuteIn<T> eat_minute(P& p, const T (&x)[13], T meal
     }
     u.bD = p(DP_B) * dsafe;
     u.dD = p(DP_D) * dsafe;
+    u.aabD = u.aa * u.bD;
+    u.ccdD = u.cc * u.dD;
     return u;
 }
 
