@@ -195,6 +195,15 @@ __device__ __forceinline__ double fdiv(double a, double b)
     return fma(fma(-b, q, a), y, q);
 }
 __device__ __forceinline__ float fdiv(float a, float b) { return __fdividef(a, b); }
+// a / b to ~3e-15 relative: the seed, one Newton step, the product; no residual correction (3 instructions less).
+// For the quotients inside the sub-step loops (gastric emptying, insulin-dependent utilisation).
+__device__ __forceinline__ double fdiv_loop(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    y = fma(y, fma(-b, y, 1.0), y);
+    return a * y;
+}
+__device__ __forceinline__ float fdiv_loop(float a, float b) { return __fdividef(a, b); }
 
 // log(v) for finite v > 0 (fdlibm-style: v = 2^e m, m in [sqrt(1/2), sqrt 2), s = f/(2+f),
 // degree-7 even polynomial in s^2); ~35 VALU ops, < 1 ulp.
@@ -448,7 +457,7 @@ __device__ __forceinline__ T kgut_flux(P& p, const MinuteIn<T>& u, T q0, T q1)
     const T a2 = t_min(sizeof(T) == 8 ? (T)fma((double)u.aa, (double)qsto, -(double)u.aabD) : u.aa * (qsto - u.bD), ehi);
     const T c2 = t_min(sizeof(T) == 8 ? (T)fma((double)u.cc, (double)qsto, -(double)u.ccdD) : u.cc * (qsto - u.dD), ehi);
     const T ea = exp_core<8>(a2), ec = exp_core<8>(c2);
-    const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv(ea - ec, (ea + T(1)) * (ec + T(1)));
+    const T kgut = p(DP_KMAX) + p(DP_DK) * fdiv_loop(ea - ec, (ea + T(1)) * (ec + T(1)));
     return kgut * q1;
 }
 
@@ -533,7 +542,7 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
         const T f3 = t_max(egp, T(0)) - p(DP_FSNC) - et - k1x3 + k2x4;                         // :165 without Rat
         d3 = (x3 >= T(0)) ? f3 : -cD;                                                          // :167
         const T vmt = p(DP_VM0) + p(DP_VMX) * X;                                               // :169
-        const T uid = fdiv(vmt * y4, p(DP_KM0) + y4);                                          // :171
+        const T uid = fdiv_loop(vmt * y4, p(DP_KM0) + y4);                                     // :171
         const T f4 = -uid + k1x3 - k2x4;                                                       // :172
         d4 = (y4 >= T(0)) ? f4 : T(0);                                                         // :173
         const T ksc = p(DP_KSC);
