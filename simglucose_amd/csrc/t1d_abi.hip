@@ -43,6 +43,9 @@ struct t1d_ctx {
     int np_pad = 0;
     double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
+    int* d_defer = nullptr;          // stepa_kernel -> stepr_kernel scratch: [tiles] counts, then [tiles][256] env indices
+    int64_t defer_tiles = 0;         // tiles d_defer was allocated for
+    int64_t defer_min_envs = 786432; // adaptive multi-minute launches take the two-launch form from this batch size up
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
 };
@@ -356,6 +359,11 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         c->pipe_stagger = (int)value;
         return T1D_OK;
     }
+    if (std::strcmp(name, "defer_min_envs") == 0) {
+        if (value < 0) return fail(T1D_E_INVALID, "t1d_ctx_set_option: defer_min_envs must be >= 0");
+        c->defer_min_envs = value;
+        return T1D_OK;
+    }
     if (std::strcmp(name, "pipe_blocks") == 0) {
         if (value < 0 || value > 65535) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipe_blocks out of range");
         c->pipe_blocks = (int)value;
@@ -395,7 +403,7 @@ extern "C" int t1d_ctx_destroy(t1d_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_par64); (void)hipFree(c->d_par32); (void)hipFree(c->d_x0);
     (void)hipFree(c->d_minv64); (void)hipFree(c->d_minv32); (void)hipFree(c->d_status);
-    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); (void)hipFree(c->d_trace);
+    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); (void)hipFree(c->d_trace); (void)hipFree(c->d_defer);
     delete c;
     return T1D_OK;
 }
@@ -439,6 +447,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.x0tab = c->d_x0;
     a.minv = sizeof(T) == 8 ? (const T*)c->d_minv64 : (const T*)c->d_minv32;
     a.status = c->d_status; a.trace = c->d_trace;
+    a.dcnt = c->d_defer; a.dseg = c->d_defer ? c->d_defer + c->defer_tiles : nullptr;
     a.sen.pacf = (T)c->sensor[0]; a.sen.gamma = (T)c->sensor[1]; a.sen.lambda = (T)c->sensor[2];
     a.sen.delta = (T)c->sensor[3]; a.sen.xi = (T)c->sensor[4]; a.sen.st = (int)c->sensor[5];
     a.sen.vmin = (T)c->sensor[6]; a.sen.vmax = (T)c->sensor[7];
@@ -570,6 +579,28 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             T1D_HIP(hipGetLastError());
             return T1D_OK;
         }
+    }
+    // adaptive scheme, any minutes per launch, refill-free, large batch: fixed-step launch that sets flagged envs aside
+    // (stepa_kernel) + a launch that redoes those with the in-place rule (stepr_kernel)
+    if (split_refill && split && (variant == 6 || variant == 7) &&
+        (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && b->n >= c->defer_min_envs))) {
+        const int64_t ntiles = (b->n + kBlock - 1) / kBlock;
+        if (c->defer_tiles < ntiles) {
+            (void)hipFree(c->d_defer); c->d_defer = nullptr; c->defer_tiles = 0;
+            T1D_HIP(hipMalloc((void**)&c->d_defer, (size_t)ntiles * (1 + kBlock) * sizeof(int)));
+            c->defer_tiles = ntiles;
+        }
+        const size_t dynr = dyn;
+        const dim3 gridr((unsigned)((ntiles + kDeferGroup * (kBlock / 64) - 1) / (kDeferGroup * (kBlock / 64))));
+        if (b->dtype == T1D_F64) {
+            hipLaunchKernelGGL(stepa_kernel<double>, grid_for(b->n), dim3(kBlock), dyn, s, make_args<double>(c, b, minutes, n_sub));
+            hipLaunchKernelGGL(stepr_kernel<double>, gridr, dim3(kBlock), dynr, s, make_args<double>(c, b, minutes, n_sub), (int)ntiles);
+        } else {
+            hipLaunchKernelGGL(stepa_kernel<float>, grid_for(b->n), dim3(kBlock), dyn, s, make_args<float>(c, b, minutes, n_sub));
+            hipLaunchKernelGGL(stepr_kernel<float>, gridr, dim3(kBlock), dynr, s, make_args<float>(c, b, minutes, n_sub), (int)ntiles);
+        }
+        T1D_HIP(hipGetLastError());
+        return T1D_OK;
     }
 #define T1D_LAUNCH_FAST(V, TT) hipLaunchKernelGGL((step_kernel<V, TT, false>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
 #define T1D_BY_VARIANT(L, TT) do { switch (variant) { case 0: L(0, TT); break; case 1: L(1, TT); break; case 2: L(2, TT); break; \

@@ -7,6 +7,8 @@
 //                      together, all lanes refining, once the CU's chunk queue is empty (the default at >= 8 chunks per CU).
 //   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
 //                      n_sub sub-steps -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
+//   stepa_kernel, stepr_kernel  step_kernel for the adaptive scheme in two launches (large multi-minute batches): fixed
+//                      steps with flagged envs set aside, then those redone with the in-place rule.
 //   refill_kernel      rebuilds due 150-minute CGM noise blocks ahead of a step kernel compiled without that code.
 //   step_pipe_kernel   step_kernel made persistent with LDS-DMA prefetch (classical RK4; experiment, off by default).
 //   rollout_pid_kernel n_steps x (PID or basal-bolus policy + step) with state in registers.
@@ -44,6 +46,7 @@ template <typename T> struct KArgs {
     const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
     int* status;
     long long* trace;       // T1D_S1_TRACE builds only: phase timestamps of the first blocks' waves
+    int* dseg; int* dcnt;   // stepa_kernel -> stepr_kernel: env indices set aside per 256-env tile [tiles][256], and how many [tiles]
     SensorC<T> sen; PumpC<T> pump;
     int np, S, n_meals, n_normals, minutes, n_sub, flags, stagger, prop_rows, np_pad;
 };
@@ -322,9 +325,13 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `pre_rk4` runs once, immediately before the first minute's RK4 sub-steps: from there to the end of
 // the integration the wave issues no vector-memory instruction, which is where the persistent kernel
 // starts the LDS-DMA of its next tile.
-template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false, bool REFILL = true, typename PR = NoProp>
+// ABORT (fixed-step split integrator, stepa_kernel): a lane that meets a minute asking for the adaptive scheme's
+// refinement stops there and reports it through *aborted; the caller stores nothing of it.
+template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false, bool REFILL = true, typename PR = NoProp,
+          bool ABORT = false>
 __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
-                                                T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook(), PR pr = PR())
+                                                T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook(), PR pr = PR(),
+                                                bool* aborted = nullptr)
 {
     T q_basal, q_bolus;
     if (a.flags & (T1D_BATCH_NO_PUMP | 0x200)) { // T1DPatient.step driven directly: insulin = basal + bolus as given
@@ -353,6 +360,12 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
         }
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
         if (m == 0) pre_rk4();
+        if constexpr (ABORT) {
+            static_assert(PR::kSplit && !PR::kAdapt && !REFILL, "abort-on-flag goes with the fixed-step split integrator");
+            const T f1 = kgut_flux(p, u, e.x[0], e.x[1]);
+            if (gut_refine_flag(u, e.x[0], e.x[1], f1)) { *aborted = true; break; }
+            if (!(a.flags & 0x800)) split_minute<T, P, PR, true>(p, pr, u, e.x, a.n_sub, f1);
+        } else
         if constexpr (PR::kSplit) { if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub); }
         else { if (!(a.flags & 0x800)) rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP); }
         e.t += 1;
@@ -456,6 +469,87 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     }
     write_outputs<MATH>(a, i, e, o, rp);
     store_env(a, i, pid, e);
+}
+
+// ---- any minutes per launch, split integrator, adaptive refinement in a launch of its own ----------------
+// step_kernel<6/7> refines in place: a wave with one flagged lane runs the extra half steps of that minute for the
+// one lane; over a 3-minute step ~3 % of the lanes are flagged at some point, so most waves pay, and the adaptive rule
+// keeps the parameters out of the VGPRs (+45 % over fixed steps at 1 Mi envs).  stepa_kernel is step_kernel<4> (fixed
+// steps, VGPR parameters) except that a lane meeting a flagged minute stops -- nothing of it has been stored: the
+// generic kernel stores at the end of the step -- and leaves its env index in its tile's segment of a scratch
+// buffer; stepr_kernel then redoes those envs with the in-place rule, each wave gathering the segments of
+// kDeferGroup tiles (~30 envs of 1 024).  Worth a second launch from ~3/4 Mi envs up (t1d_step decides).
+constexpr int kDeferGroup = 4;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void stepa_kernel(const KArgs<T> a)
+{
+    __shared__ int nab;
+    if (threadIdx.x == 0) nab = 0;
+    stage_prop(a, (T*)t1d_dyn_lds);                      // ends in a barrier
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __builtin_assume(i < (1u << 28));
+    if ((int64_t)i < a.n) {
+        const uint32_t meta = at(a.meta, i);
+        const uint32_t pid = T1D_META_PID(meta);
+        Env<T> e;
+        load_env(a, i, meta, e);
+        const T basal = at(a.basal, i);
+        const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+        const T rp = prev_risk<1>(a, e.prev_cgm);
+        ParsReg<T> p;
+        p.load(a.dpar, (int)pid);
+        PropLds<T, false> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        bool aborted = false;
+        StepOut<T> o = step_body<1, T, ParsReg<T>, NoHook, false, false, PropLds<T, false>, true>(
+            a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr, &aborted);
+        if (aborted) {
+            a.dseg[blockIdx.x * kBlock + atomicAdd(&nab, 1)] = (int)i;
+        } else {
+            write_outputs<1>(a, i, e, o, rp);
+            store_env(a, i, pid, e);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.dcnt[blockIdx.x] = nab;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock, T1D_WAVES) void stepr_kernel(const KArgs<T> a, int ntiles)
+{
+    __shared__ T lds[DP_COUNT * kMaxPatients];
+    stage_pars(a, lds, DP_COUNT);
+    stage_prop(a, (T*)t1d_dyn_lds);
+    const int lane = threadIdx.x & 63;
+    const int tile0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kDeferGroup;     // wave-uniform
+    int cnt[kDeferGroup], total = 0;
+#pragma unroll
+    for (int k = 0; k < kDeferGroup; ++k) {
+        cnt[k] = tile0 + k < ntiles ? a.dcnt[tile0 + k] : 0;
+        total += cnt[k];
+    }
+    for (int base = 0; base < total; base += 64) {       // one round unless much more than usual was set aside
+        int idx = base + lane;
+        if (idx >= total) continue;
+        int tile = tile0;
+#pragma unroll
+        for (int k = 0; k < kDeferGroup - 1; ++k)
+            if (idx >= cnt[k] && tile == tile0 + k) { idx -= cnt[k]; ++tile; }
+        const unsigned i = (unsigned)a.dseg[tile * kBlock + idx];
+        __builtin_assume(i < (1u << 28));
+        const uint32_t meta = at(a.meta, i);
+        const uint32_t pid = T1D_META_PID(meta);
+        Env<T> e;
+        load_env(a, i, meta, e);
+        const T basal = at(a.basal, i);
+        const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+        const T rp = prev_risk<1>(a, e.prev_cgm);
+        ParsLds<T> p{lds, (int)pid};
+        PropLds<T, true> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
+        StepOut<T> o = step_body<1, T, ParsLds<T>, NoHook, false, false, PropLds<T, true>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
+        write_outputs<1>(a, i, e, o, rp);
+        store_env(a, i, pid, e);
+    }
 }
 
 // ---- single-minute step, split integrator, persistent blocks -----------------------------------------

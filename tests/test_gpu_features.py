@@ -574,6 +574,45 @@ def test_deferred_refinement_equals_in_place_refinement(dtype_name):
         assert envs[0].sync() == 0 and envs[1].sync() == 0
 
 
+@pytest.mark.parametrize("dtype_name,sensor", [("f64", "Dexcom"), ("f32", "Dexcom"), ("f64", "GuardianRT")])
+def test_multi_minute_two_launch_refinement_equals_in_place(dtype_name, sensor):
+    """stepa_kernel + stepr_kernel (3- and 5-minute env.steps: lanes that meet a minute asking for refinement are set
+    aside by the fixed-step launch and redone with the in-place rule by a second launch; adaptive_gut = 3 forces that
+    form at any batch size) against step_kernel<6/7> (in place for every lane): 10 h with meals, a batch that ends
+    inside a tile, two tiles of envs sharing one meal plan (whole tiles set aside at once: several rounds per wave)."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    dt = torch.float64 if dtype_name == "f64" else torch.float32
+    n = 256 * 9 + 77
+    pid = np.arange(n) % 30
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=6 * 60, seed=13, device="cuda:0", dtype=dt)
+    mt[:, :512] = mt[:, :1]; ma[:, :512] = ma[:, :1]
+    pid[:512] = 7                                          # ... and one patient, so that they flag together
+    tol = 1e-9 if dtype_name == "f64" else 2e-3
+    b = torch.as_tensor(_basal(pid), device="cuda:0", dtype=dt)
+    ref = None
+    for form in (2, 3):
+        e = _mk(patient=pid, sensor=sensor, dtype=dt, noise="philox", seed=6, n_sub=4)
+        e.set_option("adaptive_gut", form)
+        e.set_meals(mt, ma)
+        e.reset()
+        bgs = []
+        for k in range(600 // e.minutes_per_step):
+            e.step(b * (0.5 + 0.25 * (k % 7)))
+            if k % 10 == 9:
+                bgs.append(e.bg.clone())
+        assert e.sync() == 0
+        out = (torch.stack(bgs), e.x.clone(), e.cgm.clone(), e.reward.clone(), e.t.clone(), e.risk.clone())
+        if ref is None:
+            ref = out
+        else:
+            assert torch.equal(out[4], ref[4])
+            assert float((out[0] - ref[0]).abs().max()) < tol
+            assert float((out[1] - ref[1]).abs().max()) < tol * 100
+            for j in (2, 3, 5):
+                assert float((out[j] - ref[j]).abs().max()) < tol, j
+
+
 def test_state_dict_roundtrip_and_determinism():
     import torch
     n = 512
