@@ -551,9 +551,10 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             // CU's envs fits next to the tables; adaptive_gut = 2 asks for the in-place form
             const int per_block = (nchunks + blocks - 1) / blocks;
             const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(int);
-            // (below ~8 chunks per CU the launch is latency-bound and the deferred pass is a second chunk in series:
-            // 16 384 envs 16.1 vs 15.1 us, 65 536 envs 16.7 vs 16.4 us, 131 072 envs 22 vs 27 us, 1 Mi envs 92 vs 111 us)
-            const bool defer = adapt && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= 8)) && stride == 32 &&
+            // (below ~4 chunks per CU the launch is latency-bound and the deferred pass is a second chunk in series:
+            // 1 024 envs 14.8 vs 14.0 us, 16 384 envs 15.7 vs 15.4 us, 65 536 envs 16.2 vs 16.8 us, 131 072 envs 21 vs 26 us,
+            // 1 Mi envs 87 vs 117 us)
+            const bool defer = adapt && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= 4)) && stride == 32 &&
                                dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(R, TT, ST, EX, AD) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX, AD>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
 #define T1D_LAUNCH_S1D(R, TT, EX) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<R, TT, 32, EX>, dyn1d)); \

@@ -4,7 +4,7 @@
 //   step1_kernel       the headline launch: ONE simulated minute per env.step, split integrator, one persistent
 //                      workgroup per CU whose waves draw 64-env chunks from a queue in LDS.
 //   step1d_kernel      step1_kernel for the adaptive scheme: flagged envs are set aside in an LDS list and integrated
-//                      together, all lanes refining, once the CU's chunk queue is empty (the default at >= 8 chunks per CU).
+//                      together, all lanes refining, once the CU's chunk queue is empty (the default at >= 4 chunks per CU).
 //   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
 //                      n_sub sub-steps -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
 //   stepa_kernel, stepr_kernel  step_kernel for the adaptive scheme in two launches (large multi-minute batches): fixed
