@@ -58,8 +58,11 @@ def cpu_baseline(n_envs, steps, n_sub, sensor, integ="split"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: 1 000 timed launches behind 400 untimed ones (~0.13 s in all).  The first few hundred launches after an
+    # idle GPU run ~6 % slower whatever the integrator (clocks ramping: 87.7 us per launch with 20 warm-up launches,
+    # 82.3 with 400 and with 2 000, fixed steps), so a short warm-up measures the ramp, not the steady state.
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--n-sub", type=int, default=4)
