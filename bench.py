@@ -12,7 +12,7 @@ minutes that cross a gastric-emptying transition fast unless `--fixed-step`), Ph
 With --gpus N each rank owns its own 1 Mi envs (weak scaling; independent episodes, no data-path
 collective); value = all ranks' env-steps / max-over-ranks wall time.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 1000 --warmup 400
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -63,6 +63,9 @@ def main():
     # 82.3 with 400 and with 2 000, fixed steps), so a short warm-up measures the ramp, not the steady state.
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--prewarm", type=int, default=400,
+                    help="launches ahead of the W warm-up steps that bring an idle GPU up to its running clocks (they advance the "
+                         "same envs; reported in config.prewarm_launches)")
     ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--n-sub", type=int, default=4)
@@ -125,7 +128,7 @@ def main():
     env.set_option("adaptive_gut", 0 if a.fixed_step else (2 if a.in_place else 1))
     if integ == "split" and not a.fixed_step:
         integ = "split_adaptive"
-    days = 1 + (a.steps + a.warmup) * env.minutes_per_step // 1440
+    days = 1 + (a.steps + a.warmup + a.prewarm) * env.minutes_per_step // 1440
     gs = torch.Generator(device=dev); gs.manual_seed(99 + rank)
     start_min = 0 if a.midnight_start else torch.randint(0, 1440, (n,), generator=gs, device=dev, dtype=torch.int32)
     mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=start_min, seed=1000, device=dev, dtype=dt, env_offset=rank * n)
@@ -134,7 +137,7 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(7 + rank)
     pool = [(basal0 * 2.0 * torch.rand(n, generator=g, device=dev, dtype=dt)).contiguous() for _ in range(8)]
     env.reset()
-    for k in range(a.warmup):
+    for k in range(a.prewarm + a.warmup):
         env.step(pool[k % 8])
     # One HIP event pair around the K launches of the timed region, on torch's current stream (the stream t1d_step
     # launches on): mean launch duration = elapsed / K.  (Bracketing single launches puts event packets between
@@ -193,7 +196,7 @@ def main():
             "config": {"workload": "configs[3]: %d envs per GPU, patient=i mod 30, random-action policy, "
                                    "random meal tables (episodes start at %s), %s sensor (sample_time %d min), %s integrator n_sub=%d, Philox CGM noise"
                                    % (n, "00:00" if a.midnight_start else "a random minute of the day per env", a.sensor, minutes, integ, a.n_sub),
-                       "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": minutes, "parallelism": "env-shard x%d" % world},
+                       "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": minutes, "prewarm_launches": a.prewarm, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},

@@ -1,15 +1,16 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py on the GPU box: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in passes of
-# their own (MI355X_MICROARCH.md: counters are collected without any trace domain).  Usage: tools/profile_bench.sh TAG [bench args]
+# their own (MI355X_MICROARCH.md: counters are collected without any trace domain).  The trace pass times 4 000 launches
+# behind 400 warm-up ones: rocprofv3's mean covers all 4 400, so the ~6 % slower first few hundred weigh < 1 %.  Usage: tools/profile_bench.sh TAG [bench args]
 set -e
 tag=${1:-v10}; shift || true
 root=$PWD
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/r01_stats_$tag -- python3 $root/bench.py --steps 400 --warmup 40 --no-cpu-baseline "$@" > $out/bench_prof_$tag.json 2> $out/bench_prof_$tag.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/r01_fetch_$tag -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/fetch_$tag.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/r01_write_$tag -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/write_$tag.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/r01_stats_$tag -- python3 $root/bench.py --prewarm 0 --warmup 400 --steps 4000 --no-cpu-baseline "$@" > $out/bench_prof_$tag.json 2> $out/bench_prof_$tag.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/r01_fetch_$tag -- python3 $root/bench.py --prewarm 0 --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/fetch_$tag.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/r01_write_$tag -- python3 $root/bench.py --prewarm 0 --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/write_$tag.err
 cd $root
 python3 - "$tag" <<'PY'
 import csv, glob, json, statistics, sys
