@@ -228,10 +228,9 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * accuracy; the error against a tight solve then equals that of n_sub doubled.  Default 1: in one-minute launches
  * the flagged envs are set aside and integrated together at the end of the launch (+6 % time at 1 Mi envs), in
  * multi-minute launches of >= 786 432 envs ("defer_min_envs") they are set aside too and redone by a second launch
- * (+23 % instead of +38 % at 1 Mi envs x 3 minutes); small batches (< 4 chunks of 64 envs per compute unit, where a
- * second pass in series costs more than it saves), smaller multi-minute launches and roll-outs take their extra steps
- * in place; 2 = in place everywhere; 3 = set aside wherever such a kernel exists (tests); 0 = the same steps in
- * every minute.  A context is driven from one stream at a time (the two-launch form keeps scratch in the context). */
+ * (+23 % instead of +38 % at 1 Mi envs x 3 minutes); smaller multi-minute launches, roll-outs and tables of more than
+ * 32 patients take their extra steps in place; 2 = in place everywhere; 3 = set aside wherever such a kernel exists
+ * (tests); 0 = the same steps in every minute.  A context is driven from one stream at a time (the two-launch form keeps scratch in the context). */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Host-only helper (no device needed): the tables of the split integrator for one patient row

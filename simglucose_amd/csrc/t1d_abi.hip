@@ -45,6 +45,7 @@ struct t1d_ctx {
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
     int* d_defer = nullptr;          // stepa_kernel -> stepr_kernel scratch: [tiles] counts, then [tiles][256] env indices
     int64_t defer_tiles = 0;         // tiles d_defer was allocated for
+    int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches defer the refinement from this many chunks per CU up
     int64_t defer_min_envs = 786432; // adaptive multi-minute launches take the two-launch form from this batch size up
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
@@ -359,6 +360,11 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         c->pipe_stagger = (int)value;
         return T1D_OK;
     }
+    if (std::strcmp(name, "defer_min_chunks") == 0) {
+        if (value < 0 || value > 65535) return fail(T1D_E_INVALID, "t1d_ctx_set_option: defer_min_chunks out of range");
+        c->defer_min_chunks = (int)value;
+        return T1D_OK;
+    }
     if (std::strcmp(name, "defer_min_envs") == 0) {
         if (value < 0) return fail(T1D_E_INVALID, "t1d_ctx_set_option: defer_min_envs must be >= 0");
         c->defer_min_envs = value;
@@ -551,14 +557,14 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             // CU's envs fits next to the tables; adaptive_gut = 2 asks for the in-place form
             const int per_block = (nchunks + blocks - 1) / blocks;
             const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(int);
-            // (below ~4 chunks per CU the launch is latency-bound and the deferred pass is a second chunk in series:
-            // 1 024 envs 14.8 vs 14.0 us, 16 384 envs 15.7 vs 15.4 us, 65 536 envs 16.2 vs 16.8 us, 131 072 envs 21 vs 26 us,
-            // 1 Mi envs 87 vs 117 us)
-            const bool defer = adapt && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= 4)) && stride == 32 &&
+            // (deferred vs in place: 1 024 envs 12.8 vs 14.0 us, 16 384 envs 14.8 vs 15.4 us, 65 536 envs 16.2 vs 17.3 us,
+            // 131 072 envs 21 vs 26 us, 1 Mi envs 87 vs 117 us; short launches with VGPR parameters in the deferred pass too)
+            const bool defer = adapt && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) && stride == 32 &&
                                dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(R, TT, ST, EX, AD) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX, AD>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
-#define T1D_LAUNCH_S1D(R, TT, EX) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<R, TT, 32, EX>, dyn1d)); \
-        hipLaunchKernelGGL((step1d_kernel<R, TT, 32, EX>), dim3(blocks), dim3(kS1Threads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+#define T1D_LAUNCH_S1D_(R, TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<R, TT, 32, EX, DR>, dyn1d)); \
+        hipLaunchKernelGGL((step1d_kernel<R, TT, 32, EX, DR>), dim3(blocks), dim3(kS1Threads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+#define T1D_LAUNCH_S1D(R, TT, EX) do { if (R && per_block < 32) T1D_LAUNCH_S1D_(R, TT, EX, R); else T1D_LAUNCH_S1D_(R, TT, EX, false); } while (0)
 #define T1D_S1_BY_EXTRA(R, TT, ST) do { if (adapt) { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, true); else T1D_LAUNCH_S1(R, TT, ST, false, true); } \
                                         else { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, false); else T1D_LAUNCH_S1(R, TT, ST, false, false); } } while (0)
 #define T1D_S1D_BY_EXTRA(R, TT) do { if (extra) T1D_LAUNCH_S1D(R, TT, true); else T1D_LAUNCH_S1D(R, TT, false); } while (0)
@@ -576,6 +582,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
 #undef T1D_S1D_BY_EXTRA
 #undef T1D_S1_BY_EXTRA
 #undef T1D_LAUNCH_S1D
+#undef T1D_LAUNCH_S1D_
 #undef T1D_LAUNCH_S1
             T1D_HIP(hipGetLastError());
             return T1D_OK;

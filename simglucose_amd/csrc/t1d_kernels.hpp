@@ -4,7 +4,7 @@
 //   step1_kernel       the headline launch: ONE simulated minute per env.step, split integrator, one persistent
 //                      workgroup per CU whose waves draw 64-env chunks from a queue in LDS.
 //   step1d_kernel      step1_kernel for the adaptive scheme: flagged envs are set aside in an LDS list and integrated
-//                      together, all lanes refining, once the CU's chunk queue is empty (the default at >= 4 chunks per CU).
+//                      together, all lanes refining, once the CU's chunk queue is empty (the default for one-minute launches).
 //   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
 //                      n_sub sub-steps -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
 //   stepa_kernel, stepr_kernel  step_kernel for the adaptive scheme in two launches (large multi-minute batches): fixed
@@ -788,7 +788,10 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
 // waves that find the chunk queue empty wait until every chunk of the CU is past that point and then take the
 // listed envs 64 at a time, all lanes refining.  The list holds every env of the CU's share (t1d_step sizes it),
 // so it cannot overflow; the per-lane arithmetic is that of MODE 1, lane for lane.
-template <bool REG, typename T, int STRIDE, bool EXTRA>
+// DREG: the deferred pass too takes its parameters from VGPRs.  A short launch is latency-bound and ends with that
+// pass, where LDS round trips in the dependent chains count (1 024 envs: 12.8 vs 14.8 us); it costs 3 spilled
+// registers, which a long launch is better off without (t1d_step picks by chunks per CU).
+template <bool REG, typename T, int STRIDE, bool EXTRA, bool DREG = false>
 __global__ __launch_bounds__(kS1Threads, 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
     T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1d_kernel(const KArgs<T> a,
         if (idx < total) {
             const unsigned i = (unsigned)dlist[idx];
             __builtin_assume(i < (1u << 28));
-            s1_chunk<false, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoFlag(), tr, 0);
+            s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoFlag(), tr, 0);
         }
     }
 }
