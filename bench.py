@@ -78,6 +78,8 @@ def main():
                          "wrapper draws a random start hour, so that every launch sees the day's mix of meal phases)")
     ap.add_argument("--in-place", action="store_true",
                     help="adaptive refinement in place (adaptive_gut = 2) instead of deferred to the end of the launch")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="t1d_ctx_set_option switches applied after the ones above (tuning runs), e.g. --opt dreg_max_chunks=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
@@ -128,6 +130,9 @@ def main():
     env.set_option("adaptive_gut", 0 if a.fixed_step else (2 if a.in_place else 1))
     if integ == "split" and not a.fixed_step:
         integ = "split_adaptive"
+    for kv in a.opt:
+        name, value = kv.split("=")
+        env.set_option(name, int(value))
     days = 1 + (a.steps + a.warmup + a.prewarm) * env.minutes_per_step // 1440
     gs = torch.Generator(device=dev); gs.manual_seed(99 + rank)
     start_min = 0 if a.midnight_start else torch.randint(0, 1440, (n,), generator=gs, device=dev, dtype=torch.int32)
@@ -171,9 +176,9 @@ def main():
     if rank == 0:
         tname = "double" if a.dtype == "f64" else "float"
         if integ != "rk4" and minutes == 1:
-            kernel_name = {"split": "t1d::step1_kernel<true, %s, 32, false, false>",
-                           "split_adaptive": "t1d::step1_kernel<false, %s, 32, false, true>" if a.in_place
-                                             else "t1d::step1d_kernel<true, %s, 32, false>"}[integ] % tname
+            kernel_name = {"split": "t1d::step1_kernel<%s, 32, false, false>",
+                           "split_adaptive": "t1d::step1_kernel<%s, 32, false, true>" if a.in_place
+                                             else "t1d::step1d_kernel<%s, false, false>"}[integ] % tname
         else:
             kernel_name = "t1d::step_kernel<%d, %s, false>" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname)
         traffic = a.traffic_bytes

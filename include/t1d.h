@@ -12,11 +12,17 @@
  *                       InsulinPump.basal / .bolus      simglucose/actuator/pump.py:23-39
  *                       T1DPatient.step / model         simglucose/patient/t1dpatient.py:82-208,222-236
  *                       scipy ode('dopri5').integrate   simglucose/patient/t1dpatient.py:110-113,276
- *                         (replaced by fixed-step RK4 with n_sub sub-steps per minute)
+ *                         (replaced by fixed-step schemes built on n_sub sub-steps per minute: the split
+ *                          integrator with per-minute step sizes by default, classical RK4 on request --
+ *                          t1d_ctx_set_option "integrator" / "adaptive_gut")
  *                       CGMSensor.measure / CGMNoise    simglucose/sensor/cgm.py:26-36, noise_gen.py:30-97
  *                       risk_index / risk_diff          simglucose/analysis/risk.py:5-17, env.py:27-33
  *   t1d_rollout_pid  <- SimObj.simulate loop with       simglucose/simulation/sim_engine.py:29-39
  *                       PIDController.policy            simglucose/controller/pid_ctrller.py:17-36
+ *   t1d_rollout_bb   <- the same loop with BBController  simglucose/controller/basal_bolus_ctrller.py:34-80
+ *   t1d_random_meals <- RandomScenario.create_scenario  simglucose/simulation/scenario_gen.py:33-60
+ *   t1d_outcome_stats<- percent_stats, risk_index_trace, simglucose/analysis/report.py:74-133,198-217
+ *                       CVGA_analysis
  *
  * Conventions
  *  - Every pointer inside t1d_batch is a DEVICE pointer (e.g. torch.Tensor.data_ptr()) owned by
@@ -27,7 +33,8 @@
  *    synchronise.  Asynchronous faults surface at t1d_sync or the next call.
  *  - Return value 0 = success; negative = error (see T1D_E_*), message in t1d_last_error()
  *    (thread-local).  No C++ exception crosses this boundary.
- *  - A ctx is bound to one device and is not thread-safe: one host thread/process per GPU.
+ *  - A ctx is bound to one device and is not thread-safe: one host thread/process per GPU.  Every entry point
+ *    that takes a ctx makes that device current (hipSetDevice) before it launches or allocates.
  */
 #ifndef T1D_H
 #define T1D_H
@@ -37,7 +44,7 @@
 extern "C" {
 #endif
 
-#define T1D_ABI_VERSION 1
+#define T1D_ABI_VERSION 2
 
 enum { T1D_F64 = 0, T1D_F32 = 1 };
 
@@ -52,8 +59,7 @@ enum {
 /* bits of the device status word returned through t1d_sync */
 enum {
     T1D_ST_NORMALS_EXHAUSTED = 1,   /* host-normals mode ran past n_normals rows; zeros were used */
-    T1D_ST_NONFINITE = 2,           /* some env's state became NaN/Inf */
-    T1D_ST_BAD_LAYOUT = 4           /* T1D_BATCH_WAVE_UNIFORM was set but a wave holds two patients; that wave was skipped */
+    T1D_ST_NONFINITE = 2            /* some env's state became NaN/Inf */
 };
 
 /* columns of one row of the patient table given to t1d_ctx_create (all double):
@@ -77,11 +83,8 @@ enum {
 #define T1D_META_EATING      0x100u
 #define T1D_META_CURSOR(m)   ((m) >> 16)
 
-/* t1d_batch.flags */
+/* t1d_batch.flags; any other bit is rejected with T1D_E_INVALID */
 enum {
-    /* every aligned run of 64 consecutive envs simulates ONE patient (same meta patient row):
-     * the kernels then keep that patient's parameters in scalar registers. */
-    T1D_BATCH_WAVE_UNIFORM = 1,
     /* skip the InsulinPump quantiser: insulin = basal + bolus exactly as given (drives the patient model
      * the way T1DPatient.step(Action(CHO, insulin)) does, t1dpatient.py:82) */
     T1D_BATCH_NO_PUMP = 2,
@@ -103,8 +106,8 @@ typedef struct t1d_batch {
     /* ---- state (read + written by t1d_step; written by t1d_reset).
      * PACKED layout (recommended; detected from the pointers): x, planned, last_qsto, last_food, last_cgm,
      * prev_cgm, pts are consecutive rows of ONE [44][n] buffer in that order, and t, meta, next_meal are
-     * consecutive rows of one [3][n] int32 buffer.  With it (and n a multiple of 256) t1d_step runs the
-     * persistent kernel that streams the next tile of envs into LDS while it integrates the current one. */
+     * consecutive rows of one [3][n] int32 buffer.  With it one-minute launches (minutes == 1) take the
+     * persistent single-minute kernels; any other layout runs the generic step kernel. */
     void* x;                  /* [13][n] ODE state */
     void* planned;            /* [n] planned_meal, g        (t1dpatient.py:229) */
     void* last_qsto;          /* [n] mg                     (t1dpatient.py:90)  */
@@ -199,50 +202,61 @@ int t1d_ctx_create(int hip_device, const double* patient_table, int n_patients, 
                    const double* sensor_row, const double* pump_row, t1d_ctx** out);
 int t1d_ctx_destroy(t1d_ctx* ctx);
 
-/* Tuning/diagnostic switches.  "math": 1 (default) = exp-based gastric-emptying term and
- * Newton-refined reciprocals in the ODE right-hand side; 0 = ocml tanh and IEEE divisions written
- * exactly as t1dpatient.py:138-140,171,178 writes them (A/B and parity reference).
- * "params_mode": where the ODE parameters live during the RK4 loop: 0 = re-read from the LDS table at
- * every use, 1 = gathered once per launch into vector registers (RK4 stages then run sub-system by
- * sub-system), -1 (default) = 1.
- * "split_refill": 1 (default) = when a launch takes at most one CGM sample (minutes <= sample_time) the
- * rarely needed rebuild of the 150-minute noise block runs as its own small kernel ahead of a step kernel
- * compiled without it (its registers would otherwise cost the step kernel ~20 %); 0 = always inline.
- * "scalar_params": 1 = batches flagged T1D_BATCH_WAVE_UNIFORM keep the patient row in scalar registers
- * (default 0: measured no faster than the VGPR form).
- * "pipeline": 1 = t1d_step runs the persistent kernel that streams the next tile of envs into LDS with
- * LDS-DMA while it integrates the current one (needs the packed state layout and n % 256 == 0);
- * default 0 (one 256-env tile per workgroup): measured equal within noise in round 1.
- * "pipe_blocks": grid of the persistent kernel (0 = 2 x compute units).
+/* Switches of a context.
  * "integrator": how `n_sub` sub-steps per minute replace scipy's dopri5 (t1dpatient.py:110-113,276):
- * 0 = classical RK4 on all 13 states; 1 = the split scheme -- exact propagator for the linear insulin
- * sub-system (:176-198), RK4 at n_sub steps for the stomach with the gut compartment in exponential form
- * (:133-148), RK4 at n_sub/2 steps for the glucose states with the absorbed mass shifted into the state
- * (:151-173,201-202) -- which needs math = 1 and n_sub in {2, 4, 6, 8}; -1 (default) = split whenever
- * those hold, classical RK4 otherwise.  Both meet 1e-3 mg/dL against scipy at n_sub = 4 (same error:
- * it is set by the gastric-emptying term, which both integrate alike); the persistent kernel
- * ("pipeline") integrates with classical RK4 only.
- * "adaptive_gut": 1 = the split integrator takes two gut steps of half the size in the minutes in which an
- * argument of the gastric-emptying tanh pair (t1dpatient.py:138-140) moves fast through its transition (< 1 % of
- * the env-minutes of a RandomScenario day: steep patients after large meals), which is where fixed steps lose
- * accuracy; the error against a tight solve then equals that of n_sub doubled.  Default 1: in one-minute launches
- * the flagged envs are set aside and integrated together at the end of the launch (+6 % time at 1 Mi envs), in
- * multi-minute launches of >= 786 432 envs ("defer_min_envs") they are set aside too and redone by a second launch
- * (+23 % instead of +38 % at 1 Mi envs x 3 minutes); smaller multi-minute launches, roll-outs and tables of more than
- * 32 patients take their extra steps in place; 2 = in place everywhere; 3 = set aside wherever such a kernel exists
- * (tests); 0 = the same steps in every minute.  A context is driven from one stream at a time (the two-launch form keeps scratch in the context). */
+ *   0 = classical RK4 on all 13 states;
+ *   1 = the split scheme -- exact propagator for the linear insulin sub-system (:176-198), RK4 for the stomach with the
+ *       gut compartment in exponential form (:133-148), RK4 at half as many steps for the glucose states with the
+ *       absorbed mass shifted into the state (:151-173,201-202) -- which needs math = 1 and n_sub in {2, 4, 6, 8};
+ *   -1 (default) = split whenever those hold, classical RK4 otherwise.
+ * "adaptive_gut": step sizes of the split scheme.  1 (default) = per minute and env, by a deterministic rule on the state
+ *   and the rates at the start of the minute: level 0 (gut n_sub/2 steps, glucose n_sub/4; calm minutes, ~95 % of the
+ *   env-minutes of RandomScenario days; n_sub divisible by 4), level 1 (gut n_sub, glucose n_sub/2), level 2 (gut 4 n_sub,
+ *   glucose n_sub: an argument of the gastric-emptying tanh pair, t1dpatient.py:138-140, moves fast through its
+ *   transition, a kink of the glucose sub-system -- EGP floor, renal threshold, x3 = 0, :158-167 -- is about to be
+ *   crossed, or insulin action makes the tissue compartment fast).  Max error against a tight solve 1.7e-4 mg/dL on
+ *   random-meal days (level 1 everywhere: 7e-3).  In one-minute launches the lanes of levels 1 and 2 are set aside and
+ *   integrated together at the end of the launch; elsewhere every lane takes its level in place.
+ *   0 = level 1 in every minute; 2 = as 1 but in place in every kernel; 3 = as 1, set aside at any batch size (tests).
+ * "math": 1 (default) = exp-based gastric-emptying term and Newton-refined reciprocals in the ODE right-hand side;
+ *   0 = ocml tanh and IEEE divisions written exactly as t1dpatient.py:138-140,171,178 writes them, classical RK4
+ *   (A/B and parity reference).
+ * "split_refill": 1 (default) = when a launch takes at most one CGM sample (minutes <= sample_time) the rarely needed
+ *   rebuild of the 150-minute noise block runs as its own small kernel ahead of a step kernel compiled without it (its
+ *   registers would otherwise cost the step kernel ~20 %); 0 = always inline.
+ * "single_minute_kernel": 1 (default) = one-minute launches on the packed layout take the persistent kernels.
+ * "s1_blocks": grid of those kernels (0 = one workgroup per compute unit).
+ * "defer_min_chunks", "dreg_max_chunks": thresholds (64-env chunks per workgroup) from which the set-aside form is
+ *   used, and below which its deferred passes keep their parameters in vector registers. */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Host-only helper (no device needed): the tables of the split integrator for one patient row
- * (T1D_P_* order, n_cols == T1D_P_NCOLS) and n_sub in {2, 4, 6, 8}: 14 n_sub + 21 entries of the
- * insulin propagator Phi(k/n_sub) (layout in simglucose_amd/csrc/t1d_device.hpp) followed by the four
- * weights E, wa, wm, wb of the exponential gut update for h = 1/n_sub and the same four for h/2;
- * out_len >= 14 n_sub + 29.  What t1d_step
- * uploads; exposed so that the tables can be checked against an independent matrix exponential. */
+ * (T1D_P_* order, n_cols == T1D_P_NCOLS) and n_sub in {2, 4, 6, 8}: 28 n_sub + 21 entries of the insulin propagator
+ * Phi(k / (2 n_sub)), k = 1 .. 2 n_sub (layout in simglucose_amd/csrc/t1d_device.hpp), followed by the four weights
+ * E, wa, wm, wb of the exponential gut update for the gut step of level 1 (h = 1/n_sub), of level 2 (h/4) and of
+ * level 0 (2 h); out_len >= 28 n_sub + 33.  What t1d_step uploads; exposed so that the tables can be checked against
+ * an independent matrix exponential. */
+int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
+
+/* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after
+ * T1DSimEnv.reset(): cgm = CGM sample #1, prev_cgm = CGM sample #0, bg/lbgi/hbgi/risk of the
+ * initial state, reward 0, done 0.  random_init_bg != 0 draws x[3], x[4], x[12] ~ N(mu, 0.1 mu)
+ * with Philox (statistical counterpart of t1dpatient.py:256-270; exact parity = x0_override). */
+int t1d_reset(t1d_ctx* ctx, const t1d_batch* b, const uint8_t* mask, int random_init_bg, void* hip_stream);
+
+/* Advance every env by `minutes` (normally int(sample_time)) with one kernel launch, the same
+ * action held for the whole call; integrator and step sizes as set on the context, built on n_sub sub-steps per minute. */
+int t1d_step(t1d_ctx* ctx, const t1d_batch* b, int minutes, int n_sub, void* hip_stream);
+
+/* n_steps closed-loop steps in ONE launch: basal = PID(obs CGM), bolus = 0, then as t1d_step.
+ * b->cgm must hold the current observation on entry (as left by t1d_reset / t1d_step). */
+int t1d_rollout_pid(t1d_ctx* ctx, const t1d_batch* b, const t1d_pid* pid, int n_steps, int minutes,
+                    int n_sub, void* hip_stream);
+
 /* SimObj.simulate (sim_engine.py:29-39) with BBController for n_steps env.steps in ONE launch: per step
  * basal = bb.basal; bolus = (prev_meal*sample_time/CR + (CGM > 150)*(CGM - target)/CF) / sample_time if
- * prev_meal > 0 else 0 (:66-79), where CGM is the previous step's observation (batch.cgm on entry) and
- * prev_meal the previous step's mean announced CHO; then the same step as t1d_step with meals from the
+ * prev_meal > 0 else 0 (basal_bolus_ctrller.py:66-79), where CGM is the previous step's observation (batch.cgm on
+ * entry) and prev_meal the previous step's mean announced CHO; then the same step as t1d_step with meals from the
  * meal tables.  Outputs/state as t1d_rollout_pid; bb.prev_meal is updated. */
 int t1d_rollout_bb(t1d_ctx* ctx, const t1d_batch* batch, const t1d_bb* bb, int n_steps, int minutes,
                    int n_sub, void* stream);
@@ -257,25 +271,9 @@ int t1d_random_meals(int hip_device, uint64_t seed, int64_t env_offset, int64_t 
                      const int32_t* start_minute_of_day, int start_scalar, int32_t* meal_time, void* meal_amt,
                      void* stream);
 
+/* The numbers of analysis/report.py per env from a BG history [n_rows][n] kept on the device (see t1d_outcome). */
 int t1d_outcome_stats(int hip_device, int dtype, int64_t n, int64_t n_rows, const void* bg_trace,
                       const t1d_outcome* out, void* stream);
-
-int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
-
-/* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after
- * T1DSimEnv.reset(): cgm = CGM sample #1, prev_cgm = CGM sample #0, bg/lbgi/hbgi/risk of the
- * initial state, reward 0, done 0.  random_init_bg != 0 draws x[3], x[4], x[12] ~ N(mu, 0.1 mu)
- * with Philox (statistical counterpart of t1dpatient.py:256-270; exact parity = x0_override). */
-int t1d_reset(t1d_ctx* ctx, const t1d_batch* b, const uint8_t* mask, int random_init_bg, void* hip_stream);
-
-/* Advance every env by `minutes` (normally int(sample_time)) with one kernel launch, the same
- * action held for the whole call, RK4 with n_sub sub-steps per minute. */
-int t1d_step(t1d_ctx* ctx, const t1d_batch* b, int minutes, int n_sub, void* hip_stream);
-
-/* n_steps closed-loop steps in ONE launch: basal = PID(obs CGM), bolus = 0, then as t1d_step.
- * b->cgm must hold the current observation on entry (as left by t1d_reset / t1d_step). */
-int t1d_rollout_pid(t1d_ctx* ctx, const t1d_batch* b, const t1d_pid* pid, int n_steps, int minutes,
-                    int n_sub, void* hip_stream);
 
 /* The standard normals the kernels draw in Philox mode for episode `episode`: out[r][i] = draw
  * (draw0 + r) of env (env_offset + i), doubles [n_draws][n] on the device.  Draw 0 is the AR(1)

@@ -159,28 +159,33 @@ void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double 
 }
 
 /* ------------------------------------------------------------------------------------------
- * Split fixed-step scheme over one minute (integrator 3) -- the HIP kernel's default integrator.
+ * Split scheme over one minute (integrators 3 and 4) -- what the HIP kernels integrate with.
  * Same model (t1dpatient.py:119-208), partitioned by what each part of it needs:
  *   insulin  s = (x5, x9, x10, x11, x6, x7, x8): linear with the minute's constant infusion (:176-198), so it
  *            is advanced with its exact propagator s(tau) = Phi(tau) [s; u; 1] (Phi from the host, one 7x9
- *            block per tau = k/ng); the (x >= 0) factors of :179,191,195,198 never switch on this
+ *            block per tau = k/(2 n_sub)); the (x >= 0) factors of :179,191,195,198 never switch on this
  *            non-negative linear flow and are dropped;
- *   gut      x0, x1 (:133-145): classical RK4, ng steps; F = kgut*x1 is also integrated (Q, RK4 quadrature);
+ *   gut      x0, x1 (:133-145): classical RK4; F = kgut*x1 is also integrated (Q, RK4 quadrature);
  *            x2 (:148) is linear in itself with rate kabs (up to 1.23/min): exponential form
- *            x2' = E x2 + wa F1 + wm (F2+F3)/2 + wb F4 (ETD-RK4 weights for h = 1/ng from the host);
+ *            x2' = E x2 + wa F1 + wm (F2+F3)/2 + wb F4 (ETD-RK4 weights per step size from the host);
  *            absorbed mass R = x2(0) - x2 + Q (what has left x2 through kabs since the minute began);
- *   glucose  x3, x4, x12 (:151-173,201-202): classical RK4, ns = ng/2 steps, on (z3 = x3 - c R, x4, x12),
+ *   glucose  x3, x4, x12 (:151-173,201-202): classical RK4 at half as many steps as the gut, on (z3 = x3 - c R, x4, x12),
  *            c = f/BW: the fast rate-of-appearance forcing then enters only through the argument
  *            x3 = z3 + c R(tau), with R, X = x6 and XL = x8 taken at the stage times from the parts above.
  *            The (x >= 0) factors of :167,173,202 are kept.
- * tab: [ng][7][9] Phi(k/ng), k = 1..ng, then E, wa, wm, wb for h = 1/ng and E, wa, wm, wb for h = 1/(2 ng).
- * Error vs a tight solve is the same as RK4(n_sub = ng) on the whole state (tests/test_oracle_golden.py), at
- * ~60 % of its arithmetic.
- * adapt != 0 (integrator 4): the gut takes TWO steps of h/2 per step in the minutes in which an argument of the
- * gastric-emptying tanh pair (t1dpatient.py:138-140) moves fast through its transition -- |change over the
- * minute| > 4 (predicted from the rate at the start of the minute) while passing within 3 of zero -- which is
- * where fixed steps lose their accuracy: < 1 % of the env-minutes of a RandomScenario day, and with them the
- * error against a tight solve drops to that of ng doubled everywhere (tools/random_scenario_error.py).
+ *            A step that begins with x3 < 0 holds x3 exactly (every stage of the reference's RHS returns dx3 = 0
+ *            there, :167); a step that takes x3 from >= 0 to < 0 ends at x3 = -1e-10: scipy's step-size control
+ *            (atol 1e-12) lands within ~1e-10 below zero, where the state then stays for good, and a fixed step
+ *            would overshoot by up to ~0.1 mg/kg (0.05 mg/dL held for the rest of the episode).
+ * Step sizes (integrator 3, "split": level 1 in every minute; integrator 4, "split_adaptive": per minute and env,
+ * from the state and the rates at the start of the minute -- o_tier_level below; a deterministic rule, so the HIP
+ * kernels take the same decisions):
+ *   level 0  gut n_sub/2 steps, glucose n_sub/4   calm minutes: ~95 % of the env-minutes of RandomScenario days
+ *   level 1  gut n_sub steps,   glucose n_sub/2   (n_sub = 4: RK4 at h = 1/4 and H = 1/2)
+ *   level 2  gut 4 n_sub steps, glucose n_sub     an argument of the gastric-emptying tanh pair (:138-140) moves
+ *            fast through its transition, a kink of the glucose sub-system (EGP floor :165, renal threshold
+ *            :158-161, x3 = 0 :167) is about to be crossed, or the tissue compartment is fast (large insulin action)
+ * Against a tight solve on 600 random env-days: max 1.7e-4 mg/dL (level 1 everywhere: 6.9e-3) -- tools/tier_study.py.
  * ---------------------------------------------------------------------------------------- */
 static double o_kgut(const double* p, double qsto, double Dbar)
 {
@@ -194,9 +199,10 @@ static double o_kgut(const double* p, double qsto, double Dbar)
 }
 
 static void o_glucose_rhs(const double* p, const double* y, double cR, double cRdot, double X, double XL,
-                          double* dy)
+                          double x3_frozen, double* dy)
 {
-    const double x3 = y[0] + cR, x4 = y[1], x12 = y[2];
+    /* x3_frozen < 0: the step began with x3 < 0, where the reference holds it (dx3 = 0 at every stage, :167) */
+    const double x3 = x3_frozen < 0.0 ? x3_frozen : y[0] + cR, x4 = y[1], x12 = y[2];
     const double EGPt = p[T1D_O_KP1] - p[T1D_O_KP2] * x3 - p[T1D_O_KP3] * XL;
     const double Et = (x3 > p[T1D_O_KE2]) ? p[T1D_O_KE1] * (x3 - p[T1D_O_KE2]) : 0.0;
     double d3 = (EGPt > 0.0 ? EGPt : 0.0) - p[T1D_O_FSNC] - Et - p[T1D_O_K1] * x3 + p[T1D_O_K2] * x4;
@@ -209,49 +215,97 @@ static void o_glucose_rhs(const double* p, const double* y, double cR, double cR
     dy[0] = d3; dy[1] = d4; dy[2] = d12;
 }
 
-#ifndef T1D_O_ADAPT_NEAR
-#define T1D_O_ADAPT_NEAR 3.0     /* |tanh argument| below this somewhere in the minute ... */
-#endif
-#ifndef T1D_O_ADAPT_MOVE
-#define T1D_O_ADAPT_MOVE 4.0     /* ... while it changes by more than this over the minute */
-#endif
-int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
-                       double lf, int ng, int adapt)
+/* Knobs of the step-size rule (study builds / tools may override them through t1d_o_set_knob; the defaults are what
+ * the HIP kernels hard-code):
+ *   0 NEAR   |tanh argument| below this somewhere in the minute ...
+ *   1 MOVE   ... while it changes by more than this over the minute       -> level 2 (gut)
+ *   2 CALM   both tanh arguments change by less than this over the minute  -> level 0 allowed (gut)
+ *   3 KINK2  a kink function g (EGP, x3 - ke2, x3) with min(|g0|, |g1|) < KINK2 |g1 - g0| or a sign change -> level 2
+ *   4 KINK0  min(|g0|, |g1|) < KINK0 |g1 - g0| (or a sign change)         -> level 0 not allowed
+ *   5 SNAP   x3 that a glucose step takes from >= 0 to < 0 is set to -SNAP (0 = leave it)
+ *   6 STIFF0 rate of the tissue compartment Vmt / (Km0 + x4) + k2 above this (1/min) -> level 0 not allowed
+ *   7 STIFF2 ... above this                                               -> level 2                              */
+static double o_knob[8] = {3.0, 4.0, 1.0, 1.0, 2.0, 1e-10, 0.4, 1.0};
+void t1d_o_set_knob(int k, double v) { if (k >= 0 && k < 8) o_knob[k] = v; }
+double t1d_o_get_knob(int k) { return (k >= 0 && k < 8) ? o_knob[k] : 0.0; }
+
+/* The step-size rule: level of the minute from the state and the rates at its start.  dq = d(qsto)/dt,
+ * k0[3] = glucose RHS (dz3, dx4, dx12) there, xl_dot = d(x8)/dt there. */
+static int o_tier_level(const double* p, const double* x, double Dbar, double dq, const double* k0, double xl_dot)
 {
-    if (ng < 2 || ng > 16 || (ng & 1) || !tab) return -1;
-    const int ns = ng / 2;
+    int lvl2 = 0, calm = 1;
+    if (Dbar > 0.0) {
+        const double aa = 5.0 / 2.0 / (1.0 - p[T1D_O_B]) / Dbar, cc = 5.0 / 2.0 / p[T1D_O_D] / Dbar;
+        const double q0 = x[0] + x[1];
+        const double A0 = aa * (q0 - p[T1D_O_B] * Dbar), A1 = A0 + aa * dq;
+        const double C0 = cc * (q0 - p[T1D_O_D] * Dbar), C1 = C0 + cc * dq;
+        const int fa = fabs(A1 - A0) > o_knob[1] && (A0 * A1 <= 0.0 || fmin(fabs(A0), fabs(A1)) < o_knob[0]);
+        const int fc = fabs(C1 - C0) > o_knob[1] && (C0 * C1 <= 0.0 || fmin(fabs(C0), fabs(C1)) < o_knob[0]);
+        lvl2 = fa || fc;
+        calm = fabs(A1 - A0) < o_knob[2] && fabs(C1 - C0) < o_knob[2];
+    }
+    /* kinks of the glucose sub-system (t1dpatient.py:158-167): g and its rate at the start of the minute */
+    const double x3 = x[3], d3 = k0[0];                                  /* k0[0] = dx3/dt incl. the rate of appearance */
+    const double g[3] = {p[T1D_O_KP1] - p[T1D_O_KP2] * x3 - p[T1D_O_KP3] * x[8], x3 - p[T1D_O_KE2], x3};
+    const double dg[3] = {-p[T1D_O_KP2] * d3 - p[T1D_O_KP3] * xl_dot, d3, d3};
+    for (int j = 0; j < 3; ++j) {
+        const double g1 = g[j] + dg[j], m = fmin(fabs(g[j]), fabs(g1)), ad = fabs(dg[j]);
+        if (j == 2 && g[j] < 0.0) { calm = 0; continue; }                /* x3 < 0: held (:167), no kink ahead; never level 0 */
+        if (g[j] * g1 <= 0.0 || m < o_knob[3] * ad) lvl2 = 1;
+        if (g[j] * g1 <= 0.0 || m < o_knob[4] * ad) calm = 0;
+    }
+    /* insulin-dependent utilisation (:169-172) makes the tissue compartment fast under large insulin action */
+    const double lam4 = (p[T1D_O_VM0] + p[T1D_O_VMX] * x[6]) / (p[T1D_O_KM0] + x[4]) + p[T1D_O_K2];
+    if (lam4 > o_knob[6]) calm = 0;
+    if (lam4 > o_knob[7]) lvl2 = 1;
+    return lvl2 ? 2 : (calm ? 0 : 1);
+}
+
+/* tab: [2 n_sub][7][9] Phi(k / (2 n_sub)), k = 1 .. 2 n_sub, then (E, wa, wm, wb) for h = 2/n_sub, 1/n_sub, 1/(4 n_sub).
+ * mode 0: level 1 in every minute (gut n_sub steps, glucose n_sub/2: the fixed-step "split" scheme);
+ * mode 1: level by o_tier_level -- 0: gut n_sub/2 steps, glucose n_sub/4 (n_sub divisible by 4, else level 1);
+ *         1: as mode 0; 2: gut 4 n_sub steps (two per glucose half step), glucose n_sub.
+ * Returns the level used, or -1 on bad arguments. */
+int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
+                       double lf, int n_sub, int mode)
+{
+    if (n_sub < 2 || n_sub > 8 || (n_sub & 1) || !tab) return -1;
+    const int nb = 2 * n_sub;
     const double d = cho * 1000.0, u = ins * 6000.0 / p[T1D_O_BW], Dbar = lq + lf * 1000.0;
     const double kmax = p[T1D_O_KMAX], kabs = p[T1D_O_KABS], c = p[T1D_O_F] / p[T1D_O_BW];
     static const int SI[7] = {5, 9, 10, 11, 6, 7, 8};
+    double y[3] = {x[3], x[4], x[12]}, k1[3], k2[3], k3[3], k4[3], w[3];
+    int level = 1;
+    if (mode == 1) {
+        const double F1 = o_kgut(p, x[0] + x[1], Dbar) * x[1];
+        double k0[3];
+        o_glucose_rhs(p, y, 0.0, 0.0, x[6], x[8], 0.0, k0);                /* dz3 without the Rat term ... */
+        k0[0] += (x[3] >= 0.0) ? c * kabs * x[2] : 0.0;                 /* ... so dx3 = dz3 + c kabs x2 (:151,165) */
+        level = o_tier_level(p, x, Dbar, d - F1, k0, -p[T1D_O_KI] * (x[8] - x[7]));
+        if (level == 0 && (n_sub & 3)) level = 1;
+    }
+    const int gm = level == 2 ? 2 : 1;                                              /* gut steps per glucose half step */
+    const int nh = level == 0 ? n_sub / 2 : (level == 1 ? n_sub : 2 * n_sub);      /* glucose half steps */
+    const int ng = nh * gm;                                                         /* gut steps */
+    const int ns = nh / 2;                                                          /* glucose steps */
+    const int sb = nb / nh;                                                         /* table blocks per glucose half step */
     /* insulin: exact propagation to every tau = k/ng */
     double aug[9], S[17][7];
     for (int j = 0; j < 7; ++j) { aug[j] = x[SI[j]]; S[0][j] = aug[j]; }
     aug[7] = u; aug[8] = 1.0;
-    for (int k = 1; k <= ng; ++k)
+    for (int k = 1; k <= nh; ++k)
         for (int i = 0; i < 7; ++i) {
             double a = 0.0;
-            for (int j = 0; j < 9; ++j) a += tab[((k - 1) * 7 + i) * 9 + j] * aug[j];
+            for (int j = 0; j < 9; ++j) a += tab[((k * sb - 1) * 7 + i) * 9 + j] * aug[j];
             S[k][i] = a;
         }
-    double E = tab[ng * 63], wa = tab[ng * 63 + 1], wm = tab[ng * 63 + 2], wb = tab[ng * 63 + 3];
+    const double* wt = tab + nb * 63 + 4 * level;
+    const double E = wt[0], wa = wt[1], wm = wt[2], wb = wt[3];
     /* gut */
-    double h = 1.0 / (double)ng;
-    double g0 = x[0], g1 = x[1], x2 = x[2], Q = 0.0, R[17], X2[17];
+    const double h = 1.0 / (double)ng;
+    double g0 = x[0], g1 = x[1], x2 = x[2], Q = 0.0, R[33], X2[33];
     R[0] = 0.0; X2[0] = x2;
-    int mref = 1;
-    if (adapt && Dbar > 0.0) {
-        const double aa = 5.0 / 2.0 / (1.0 - p[T1D_O_B]) / Dbar, cc = 5.0 / 2.0 / p[T1D_O_D] / Dbar;
-        const double q0 = g0 + g1, dq = d - o_kgut(p, q0, Dbar) * g1;          /* d(qsto)/dt at the start of the minute */
-        const double A0 = aa * (q0 - p[T1D_O_B] * Dbar), A1 = A0 + aa * dq;
-        const double C0 = cc * (q0 - p[T1D_O_D] * Dbar), C1 = C0 + cc * dq;
-        const int fa = fabs(A1 - A0) > T1D_O_ADAPT_MOVE && (A0 * A1 <= 0.0 || fmin(fabs(A0), fabs(A1)) < T1D_O_ADAPT_NEAR);
-        const int fc = fabs(C1 - C0) > T1D_O_ADAPT_MOVE && (C0 * C1 <= 0.0 || fmin(fabs(C0), fabs(C1)) < T1D_O_ADAPT_NEAR);
-        if (fa || fc) {
-            mref = 2; h *= 0.5;
-            E = tab[ng * 63 + 4]; wa = tab[ng * 63 + 5]; wm = tab[ng * 63 + 6]; wb = tab[ng * 63 + 7];
-        }
-    }
-    for (int s = 0; s < ng * mref; ++s) {
+    for (int s = 0; s < ng; ++s) {
         double a0, a1, F1, F2, F3, F4, b0, b1, c0, c1, e0, e1, y0, y1;
         F1 = o_kgut(p, g0 + g1, Dbar) * g1; a0 = -kmax * g0 + d; a1 = kmax * g0 - F1;
         y0 = g0 + 0.5 * h * a0; y1 = g1 + 0.5 * h * a1;
@@ -264,26 +318,33 @@ int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho
         g1 += h / 6.0 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
         Q += h / 6.0 * (F1 + 2.0 * F2 + 2.0 * F3 + F4);
         x2 = E * x2 + wa * F1 + wm * (0.5 * (F2 + F3)) + wb * F4;
-        if ((s + 1) % mref == 0) { X2[(s + 1) / mref] = x2; R[(s + 1) / mref] = x[2] - x2 + Q; }
+        if ((s + 1) % gm == 0) { X2[(s + 1) / gm] = x2; R[(s + 1) / gm] = x[2] - x2 + Q; }
     }
-    /* glucose */
+    /* glucose: x3 itself is carried from step to step (z3 = x3 - c R is formed per step), so that a held x3 stays
+     * bit for bit what it was in any precision */
     const double H = 1.0 / (double)ns;
-    double y[3] = {x[3], x[4], x[12]}, k1[3], k2[3], k3[3], k4[3], w[3];
+    double x3a = x[3];
     for (int s = 0; s < ns; ++s) {
         const int ia = 2 * s, im = 2 * s + 1, ib = 2 * s + 2;
-        o_glucose_rhs(p, y, c * R[ia], c * kabs * X2[ia], S[ia][4], S[ia][6], k1);
+        const double fz = x3a < 0.0 ? x3a : 0.0;
+        y[0] = x3a - c * R[ia];
+        o_glucose_rhs(p, y, c * R[ia], c * kabs * X2[ia], S[ia][4], S[ia][6], fz, k1);
         for (int i = 0; i < 3; ++i) w[i] = y[i] + 0.5 * H * k1[i];
-        o_glucose_rhs(p, w, c * R[im], c * kabs * X2[im], S[im][4], S[im][6], k2);
+        o_glucose_rhs(p, w, c * R[im], c * kabs * X2[im], S[im][4], S[im][6], fz, k2);
         for (int i = 0; i < 3; ++i) w[i] = y[i] + 0.5 * H * k2[i];
-        o_glucose_rhs(p, w, c * R[im], c * kabs * X2[im], S[im][4], S[im][6], k3);
+        o_glucose_rhs(p, w, c * R[im], c * kabs * X2[im], S[im][4], S[im][6], fz, k3);
         for (int i = 0; i < 3; ++i) w[i] = y[i] + H * k3[i];
-        o_glucose_rhs(p, w, c * R[ib], c * kabs * X2[ib], S[ib][4], S[ib][6], k4);
+        o_glucose_rhs(p, w, c * R[ib], c * kabs * X2[ib], S[ib][4], S[ib][6], fz, k4);
         for (int i = 0; i < 3; ++i) y[i] += H / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        double x3b = y[0] + c * R[ib];
+        if (fz < 0.0) x3b = x3a;                                        /* held */
+        else if (o_knob[5] > 0.0 && x3b < 0.0) x3b = -o_knob[5];        /* crossed zero in this step */
+        x3a = x3b;
     }
     x[0] = g0; x[1] = g1; x[2] = x2;
-    x[3] = y[0] + c * R[ng]; x[4] = y[1]; x[12] = y[2];
-    for (int j = 0; j < 7; ++j) x[SI[j]] = S[ng][j];
-    return 0;
+    x[3] = x3a; x[4] = y[1]; x[12] = y[2];
+    for (int j = 0; j < 7; ++j) x[SI[j]] = S[nh][j];
+    return level;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -546,9 +607,11 @@ int t1d_o_step(t1d_o_batch* b, const double* basal, const double* bolus, const d
             } else if (integrator == 3) {
                 if (t1d_o_split_minute(p, b->split_tab ? b->split_tab + (size_t)b->pid[i] * b->split_stride : NULL, x,
                                        to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub, 0) < 0) rc = -1;
+                if (b->level_count) b->level_count[1]++;
             } else if (integrator == 4) {
-                if (t1d_o_split_minute(p, b->split_tab ? b->split_tab + (size_t)b->pid[i] * b->split_stride : NULL, x,
-                                       to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub, 1) < 0) rc = -1;
+                const int lv = t1d_o_split_minute(p, b->split_tab ? b->split_tab + (size_t)b->pid[i] * b->split_stride : NULL, x,
+                                                  to_eat, insulin, b->last_qsto[i], b->last_food[i], n_sub, 1);
+                if (lv < 0) rc = -1; else if (b->level_count) b->level_count[lv]++;
             } else {
                 if (t1d_o_dopri5_minute(p, x, to_eat, insulin, b->last_qsto[i], b->last_food[i],
                                         &b->h_carry[i], dopri_beta, (double)b->t[i]) < 0) rc = -1;

@@ -47,8 +47,9 @@ typedef struct {
     int32_t* n_samples;        /* [n] noise samples handed out */
     int32_t* n_draws;          /* [n] normals consumed */
     double* prev_cgm;          /* [n] CGM_hist[-1] before this step (default reward) */
-    const double* split_tab;   /* [n_patients][split_stride] tables of the split scheme (integrator 3) or NULL */
-    int32_t split_stride;      /* = n_sub * 63 + 8 */
+    const double* split_tab;   /* [n_patients][split_stride] tables of the split scheme (integrators 3, 4) or NULL */
+    int32_t split_stride;      /* = 126 n_sub + 12 */
+    int64_t* level_count;      /* [3] or NULL: env-minutes integrated at level 0 / 1 / 2 of the split scheme (studies) */
 } t1d_o_batch;
 
 typedef struct {
@@ -60,7 +61,9 @@ void t1d_o_rhs(const double* p, const double* x, double cho, double ins, double 
 void t1d_o_rk4_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int n_sub);
 void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double lq, double lf, int ng, int ns);
 int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
-                       double lf, int ng, int adapt);
+                       double lf, int n_sub, int mode);
+void t1d_o_set_knob(int k, double v);
+double t1d_o_get_knob(int k);
 int t1d_o_dopri5_minute(const double* p, double* y, double cho, double ins, double lq, double lf,
                         double* h_carry, double beta, double t_start);
 double t1d_o_pump(double amount, double inc, double lo, double hi);

@@ -104,7 +104,8 @@ class _Batch(C.Structure):
                 ("normals", _d), ("sensor", C.c_double * 8), ("pump", C.c_double * 6),
                 ("x", _d), ("planned", _d), ("last_qsto", _d), ("last_food", _d), ("was_eating", _u),
                 ("t", _i), ("h_carry", _d), ("last_cgm", _d), ("ar_e", _d), ("pts", _d),
-                ("n_samples", _i), ("n_draws", _i), ("prev_cgm", _d), ("split_tab", _d), ("split_stride", C.c_int32)]
+                ("n_samples", _i), ("n_draws", _i), ("prev_cgm", _d), ("split_tab", _d), ("split_stride", C.c_int32),
+                ("level_count", C.POINTER(C.c_int64))]
 
 
 class _Out(C.Structure):
@@ -135,6 +136,8 @@ def lib():
         L.t1d_o_split_minute.argtypes = [_d, _d, _d, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         L.t1d_o_split_minute.restype = C.c_int
         L.t1d_o_patient_minute.restype = C.c_int
+        L.t1d_o_set_knob.argtypes = [C.c_int, C.c_double]
+        L.t1d_o_get_knob.argtypes = [C.c_int]; L.t1d_o_get_knob.restype = C.c_double
         _lib = L
     return _lib
 
@@ -166,16 +169,17 @@ _INTEG = {"rk4": 0, "dopri": 1, "mr": 2, "split": 3, "split_adaptive": 4}
 
 
 def split_tables(ptab, n_sub):
-    """Host tables of the split scheme (t1d_oracle.c, integrator 3) for every row of `ptab`:
-    [n_sub][7][9] exact propagators Phi(k/n_sub) of the linear insulin sub-system
+    """Host tables of the split scheme (t1d_oracle.c, integrators 3 and 4) for every row of `ptab`:
+    [2 n_sub][7][9] exact propagators Phi(k / (2 n_sub)) of the linear insulin sub-system
     s = (x5, x9, x10, x11, x6, x7, x8) augmented with (u, 1)  (t1dpatient.py:176-198), from
-    scipy.linalg.expm, then the ETD-RK4 weights (E, wa, wm, wb) of x2' = -kabs x2 + F for
-    h = 1/n_sub by Gauss-Legendre quadrature of the quadratic interpolant against exp(-kabs (h-s))."""
+    scipy.linalg.expm, then the ETD-RK4 weights (E, wa, wm, wb) of x2' = -kabs x2 + F for the gut steps of the
+    three levels, h = 2/n_sub, 1/n_sub, 1/(4 n_sub), by Gauss-Legendre quadrature of the quadratic interpolant
+    against exp(-kabs (h-s))."""
     from scipy.linalg import expm
     ptab = np.atleast_2d(ptab)
-    out = np.zeros((ptab.shape[0], n_sub * 63 + 8))
+    nb = 2 * n_sub
+    out = np.zeros((ptab.shape[0], nb * 63 + 12))
     gx, gw = np.polynomial.legendre.leggauss(32)
-    h = 1.0 / n_sub
     for r, p in enumerate(ptab):
         g = lambda k: p[IDX[k]]
         A = np.zeros((9, 9))
@@ -186,17 +190,21 @@ def split_tables(ptab, n_sub):
         A[4, 4] = -g("p2u"); A[4, 0] = g("p2u") / g("Vi"); A[4, 8] = -g("p2u") * g("Ib")              # x6  :182
         A[5, 5] = -g("ki"); A[5, 0] = g("ki") / g("Vi")                                               # x7  :185
         A[6, 6] = -g("ki"); A[6, 5] = g("ki")                                                         # x8  :187
-        for k in range(1, n_sub + 1):
-            out[r, (k - 1) * 63:k * 63] = expm(A * (k * h))[:7].ravel()
-        for part, hh in ((0, h), (1, h / 2.0)):               # weights for h and for the refined step h/2 ("split_adaptive")
+        for k in range(1, nb + 1):
+            out[r, (k - 1) * 63:k * 63] = expm(A * (k / nb))[:7].ravel()
+        for part, hh in enumerate((2.0 / n_sub, 1.0 / n_sub, 0.25 / n_sub)):     # gut step of level 0, 1, 2
             ss = (gx + 1.0) * hh / 2.0; ww = gw * hh / 2.0
             Lah = (ss - hh / 2) * (ss - hh) / ((0 - hh / 2) * (0 - hh))
             Lmh = (ss - 0) * (ss - hh) / ((hh / 2) * (hh / 2 - hh))
             Lbh = (ss - 0) * (ss - hh / 2) / (hh * (hh / 2))
             ker = np.exp(-g("kabs") * (hh - ss))
-            out[r, n_sub * 63 + 4 * part:n_sub * 63 + 4 * part + 4] = (np.exp(-g("kabs") * hh), (ker * Lah * ww).sum(),
-                                                                      (ker * Lmh * ww).sum(), (ker * Lbh * ww).sum())
+            out[r, nb * 63 + 4 * part:nb * 63 + 4 * part + 4] = (np.exp(-g("kabs") * hh), (ker * Lah * ww).sum(),
+                                                                (ker * Lmh * ww).sum(), (ker * Lbh * ww).sum())
     return np.ascontiguousarray(out)
+
+
+def set_knob(k, v):
+    lib().t1d_o_set_knob(int(k), float(v))
 
 
 class PatientOracle:
@@ -262,6 +270,8 @@ class OracleEnv:
         if integrator in ("split", "split_adaptive"):
             self.split_tab = split_tables(self.ptab, n_sub)
             b.split_tab = _p(self.split_tab); b.split_stride = self.split_tab.shape[1]
+        self.level_count = np.zeros(3, np.int64)
+        b.level_count = self.level_count.ctypes.data_as(C.POINTER(C.c_int64))
         b.was_eating = _p(self.was_eating, _u); b.t = _p(self.t, _i)
         b.n_samples = _p(self.n_samples, _i); b.n_draws = _p(self.n_draws, _i)
         o = self._o = _Out()

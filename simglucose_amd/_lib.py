@@ -12,8 +12,8 @@ SOURCES = [os.path.join(_PKG, "csrc", "t1d_abi.hip"), os.path.join(_PKG, "csrc",
            os.path.join(_ROOT, "include", "t1d.h")]
 
 T1D_F64, T1D_F32 = 0, 1
-T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE, T1D_ST_BAD_LAYOUT = 1, 2, 4
-T1D_BATCH_WAVE_UNIFORM = 1
+T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE = 1, 2
+ABI_VERSION = 2
 T1D_BATCH_NO_PUMP = 2
 T1D_BATCH_NO_REFILL_DUE = 4
 P_NCOLS = 45
@@ -135,7 +135,7 @@ def lib():
     for name in EXPORTS:
         if name not in ("t1d_last_error",):
             getattr(L, name).restype = C.c_int
-    if L.t1d_abi_version() != 1:
+    if L.t1d_abi_version() != ABI_VERSION:
         raise T1DError("libt1d_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -3,8 +3,9 @@
 The host side holds the batched state as struct-of-arrays PyTorch-ROCm tensors (env index fastest)
 and hands their device pointers to libt1d_hip.so through the C ABI of include/t1d.h.  Semantics per
 env are those of the reference's ``simglucose/simulation/env.py`` ``T1DSimEnv.reset/step`` composed
-of ``T1DPatient`` + ``CGMSensor`` + ``InsulinPump`` + a meal scenario; the ODE integrator is
-fixed-step RK4 (``n_sub`` sub-steps per minute) instead of SciPy's adaptive DOPRI5.
+of ``T1DPatient`` + ``CGMSensor`` + ``InsulinPump`` + a meal scenario; instead of SciPy's adaptive DOPRI5 the ODE is
+integrated by the library's split scheme built on ``n_sub`` sub-steps per minute, with per-minute step sizes chosen by a
+deterministic rule (``adaptive_gut``), or by classical RK4 (``set_option("integrator", 0)``).
 """
 import ctypes as C
 
@@ -111,11 +112,7 @@ class BatchedT1DSimEnv:
             tns = getattr(self, k)
             setattr(b, k, tns.data_ptr() if tns is not None else None)
         b.n_meals = 0; b.n_normals = 0
-        # patient-homogeneous waves (aligned runs of 64 envs) let the kernels hold parameters in SGPRs
-        pad = (-self.n) % 64
-        runs = np.concatenate([pid, np.full(pad, pid[-1])]).reshape(-1, 64)
-        self.wave_uniform = bool((runs == runs[:, :1]).all())
-        b.flags = (_lib.T1D_BATCH_WAVE_UNIFORM if self.wave_uniform else 0) | (0 if use_pump else _lib.T1D_BATCH_NO_PUMP)
+        b.flags = 0 if use_pump else _lib.T1D_BATCH_NO_PUMP
         if noise not in ("philox", "host"):
             raise ValueError("noise must be 'philox' or 'host'")
         self.noise = noise
@@ -160,7 +157,8 @@ class BatchedT1DSimEnv:
         self.next_meal.copy_(mt[0])
 
     def set_option(self, name, value):
-        """t1d_ctx_set_option: e.g. ("math", 0) selects the ocml-tanh / IEEE-division RHS variant."""
+        """t1d_ctx_set_option (include/t1d.h): e.g. ("integrator", 0) = classical RK4, ("adaptive_gut", 0) = the split
+        scheme at level 1 in every minute, ("math", 0) = the ocml-tanh / IEEE-division RHS with classical RK4."""
         _lib.check(self._L.t1d_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def _stream(self):
@@ -214,13 +212,18 @@ class BatchedT1DSimEnv:
             due = any((t1 % st == 0) and ((1 + t1 // st) % S == 0) for t1 in range(self._clock + 1, self._clock + minutes + 1))
             if not due:
                 b.flags = self._flags0 | _lib.T1D_BATCH_NO_REFILL_DUE
-            self._clock += minutes
+        clock, self._clock = self._clock, None        # the shadow clock survives only a call that went through
         with torch.cuda.device(self.device):
             _lib.check(self._L.t1d_step(self._ctx, C.byref(b), minutes, self.n_sub, self._stream()))
+        if clock is not None:
+            self._clock = clock + minutes
         self._keep = (bas, cho)
         return self.cgm, self.reward, self.done, self.info()
 
     def info(self):
+        """live views of the device outputs and state: read-only for the caller (the reference's info['patient_state']
+        is the solver's own array too, env.py:112); writing env.t / env.x directly desynchronises the host's shadow
+        clock -- go through load_state_dict, which drops it."""
         return {"sample_time": self.sample_time, "bg": self.bg, "lbgi": self.lbgi, "hbgi": self.hbgi,
                 "risk": self.risk, "meal": self.meal, "insulin": self.insulin, "patient_state": self.x,
                 "t": self.t}
@@ -271,11 +274,12 @@ class BatchedT1DSimEnv:
         self._set_trace(p, trace, n_steps)
         self._b.cho = None
         self._b.flags = self._flags0
-        if self._clock is not None:
-            self._clock += int(n_steps) * self.minutes_per_step
+        clock, self._clock = self._clock, None
         with torch.cuda.device(self.device):
             _lib.check(self._L.t1d_rollout_pid(self._ctx, C.byref(self._b), C.byref(p), int(n_steps),
                                                self.minutes_per_step, self.n_sub, self._stream()))
+        if clock is not None:
+            self._clock = clock + int(n_steps) * self.minutes_per_step
         return pid_state
 
     def bb_constants(self):
@@ -311,11 +315,12 @@ class BatchedT1DSimEnv:
         self._set_trace(p, trace, n_steps)
         self._b.cho = None
         self._b.flags = self._flags0
-        if self._clock is not None:
-            self._clock += int(n_steps) * self.minutes_per_step
+        clock, self._clock = self._clock, None
         with torch.cuda.device(self.device):
             _lib.check(self._L.t1d_rollout_bb(self._ctx, C.byref(self._b), C.byref(p), int(n_steps),
                                               self.minutes_per_step, self.n_sub, self._stream()))
+        if clock is not None:
+            self._clock = clock + int(n_steps) * self.minutes_per_step
         return bb_state
 
     def philox_normals(self, n_draws, draw0=0, episode=1):

@@ -27,26 +27,20 @@ struct t1d_ctx {
     double* d_minv64 = nullptr; float* d_minv32 = nullptr;
     int* d_status = nullptr;
     int math = 1;            // RHS arithmetic variant (t1d_ctx_set_option "math")
-    int scalar_params = 0;   // 1 = wave-uniform batches use the SGPR-parameter kernels
-    int params_mode = -1;    // 0 = LDS re-read per RHS evaluation, 1 = gathered once into VGPRs, -1 = by minutes per launch
-    int pipeline = 0;        // 1 = persistent LDS-DMA pipelined step kernel, 0 = one tile per block
     int n_cu = 256;
     int lds_per_block = 65536;   // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
     std::vector<const void*> lds_allowed;   // kernels whose dynamic-LDS ceiling has been raised above 64 KiB
-    int pipe_blocks = 0;     // > 0: grid of the persistent kernel (tests exercise several tiles per block)
+    int s1_blocks = 0;       // > 0: grid of the single-minute kernels (tests exercise many chunks per block)
     int split_refill = 1;    // 1 = noise-block refills run in their own kernel ahead of a refill-free step kernel
-    int pipe_stagger = 0;    // s_sleep(127) iterations (~3.4 us each) by which the second half of the persistent grid starts late
-    int adaptive_gut = 1;    // 1 (default) = the split integrator halves the gut step in minutes that cross a gastric-emptying transition fast
-    int single_minute_kernel = 1;   // 1 = minutes == 1 launches of the split integrator use the persistent early-store kernel
+    int adaptive_gut = 1;    // 1 (default) = the split integrator picks its step sizes per minute and env; 0 = level 1 everywhere
+    int single_minute_kernel = 1;   // 1 = minutes == 1 launches of the split integrator use the persistent early-store kernels
     int integrator = -1;     // 0 = classical RK4 on all 13 states, 1 = split scheme, -1 = split whenever n_sub allows it
     int split_nsub = 0;      // n_sub the split tables on the device were built for (0 = none yet)
     int np_pad = 0;
     double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
-    int* d_defer = nullptr;          // stepa_kernel -> stepr_kernel scratch: [tiles] counts, then [tiles][256] env indices
-    int64_t defer_tiles = 0;         // tiles d_defer was allocated for
-    int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches defer the refinement from this many chunks per CU up
-    int64_t defer_min_envs = 786432; // adaptive multi-minute launches take the two-launch form from this batch size up
+    int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of levels 1, 2 aside from this many chunks per CU up
+    int dreg_max_chunks = 32;        // ... and run the deferred passes with VGPR parameters below this many chunks per CU
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
 };
@@ -126,12 +120,12 @@ static void mat_expm(int n, const double* A, double* E)
     }
 }
 
-// One patient row -> kPropRows(ng) propagator entries (layout: t1d_device.hpp) followed by the four x2
-// weights E, wa, wm, wb for h = 1/ng and the same four for h/2 (adaptive gut refinement).  The insulin sub-system in the order s = (x5, x9, x10, x11, x6, x7, x8, u, 1)
-// (t1dpatient.py:176-198); weights of x2' = -kabs x2 + F (:148) for h = 1/ng from the moments
-// I_k = int_0^1 exp(-z (1 - s)) s^k ds = sum_j (-z)^j k! / (k + j + 1)!,  z = kabs h, of the quadratic
-// through F(0), F(h/2), F(h).
-static void split_tables_row(const double* r, int ng, double* out)
+// One patient row -> kPropRows(n_sub) propagator entries (layout: t1d_device.hpp) followed by the four x2 weights
+// E, wa, wm, wb for the gut step of level 1 (h = 1/n_sub), of level 2 (h/4) and of level 0 (2 h).  The insulin
+// sub-system in the order s = (x5, x9, x10, x11, x6, x7, x8, u, 1) (t1dpatient.py:176-198); weights of
+// x2' = -kabs x2 + F (:148) from the moments I_k = int_0^1 exp(-z (1 - s)) s^k ds = sum_j (-z)^j k! / (k + j + 1)!,
+// z = kabs h, of the quadratic through F(0), F(h/2), F(h).
+static void split_tables_row(const double* r, int n_sub, double* out)
 {
     double A[81] = {0.0};
     auto at = [&](int i, int j) -> double& { return A[i * 9 + j]; };
@@ -143,16 +137,17 @@ static void split_tables_row(const double* r, int ng, double* out)
     at(5, 5) = -r[T1D_P_KI]; at(5, 0) = r[T1D_P_KI] / r[T1D_P_VI];
     at(6, 6) = -r[T1D_P_KI]; at(6, 5) = r[T1D_P_KI];
     double Ah[81], Ph[81], Pk[81], tmp[81];
-    const double h = 1.0 / (double)ng;
-    for (int k = 0; k < 81; ++k) Ah[k] = A[k] * h;
+    const int nb = 2 * n_sub;                            // blocks: tau = k / nb
+    const double hb = 1.0 / (double)nb;
+    for (int k = 0; k < 81; ++k) Ah[k] = A[k] * hb;
     mat_expm(9, Ah, Ph);
     std::memcpy(Pk, Ph, sizeof(Pk));
     static const int c6[7] = {4, 0, 1, 2, 3, 7, 8};      // x6 <- x6, x5, x9, x10, x11, u, 1
     static const int c8[7] = {6, 5, 0, 1, 2, 3, 7};      // x8 <- x8, x7, x5, x9, x10, x11, u
-    for (int k = 1; k <= ng; ++k) {
+    for (int k = 1; k <= nb; ++k) {
         double* o = out + (k - 1) * 14;
         for (int j = 0; j < 7; ++j) { o[j] = Pk[4 * 9 + c6[j]]; o[7 + j] = Pk[6 * 9 + c8[j]]; }
-        if (k == ng) break;
+        if (k == nb) break;
         for (int i = 0; i < 9; ++i)
             for (int j = 0; j < 9; ++j) {
                 double v = 0.0;
@@ -161,15 +156,17 @@ static void split_tables_row(const double* r, int ng, double* out)
             }
         std::memcpy(Pk, tmp, sizeof(Pk));
     }
-    double* t = out + 14 * ng;                           // tail: Phi(1)
+    double* t = out + 14 * nb;                           // tail: Phi(1)
     static const int c5[5] = {0, 1, 2, 3, 7};
     for (int j = 0; j < 5; ++j) { t[j] = Pk[0 * 9 + c5[j]]; t[5 + j] = Pk[1 * 9 + c5[j]]; }
     t[10] = Pk[2 * 9 + 2]; t[11] = Pk[2 * 9 + 7];
     t[12] = Pk[3 * 9 + 2]; t[13] = Pk[3 * 9 + 3]; t[14] = Pk[3 * 9 + 7];
     static const int c7[6] = {5, 0, 1, 2, 3, 7};
     for (int j = 0; j < 6; ++j) t[15 + j] = Pk[5 * 9 + c7[j]];
-    for (int part = 0; part < 2; ++part) {               // weights for h, then for the refined step h/2
-        const double hh = part ? 0.5 * h : h, z = r[T1D_P_KABS] * hh;
+    const double h1 = 1.0 / (double)n_sub;
+    const double hs[3] = {h1, 0.25 * h1, 2.0 * h1};      // gut step of level 1, 2, 0 (the order of DP_X2E, DP_X2E2, DP_X2E0)
+    for (int part = 0; part < 3; ++part) {
+        const double hh = hs[part], z = r[T1D_P_KABS] * hh;
         double I[3];
         for (int k = 0; k < 3; ++k) {
             double term = 1.0, sum = 0.0;                // term = (-z)^j k! / (k + j + 1)!
@@ -182,7 +179,7 @@ static void split_tables_row(const double* r, int ng, double* out)
             }
             I[k] = sum;
         }
-        double* w = out + kPropRows(ng) + 4 * part;
+        double* w = out + kPropRows(n_sub) + 4 * part;
         w[0] = std::exp(-z);
         w[1] = hh * (2.0 * I[2] - 3.0 * I[1] + I[0]);
         w[2] = hh * (-4.0 * I[2] + 4.0 * I[1]);
@@ -195,7 +192,7 @@ extern "C" int t1d_split_tables(const double* patient_row, int n_cols, int n_sub
     if (!patient_row || !out) return fail(T1D_E_INVALID, "t1d_split_tables: NULL argument");
     if (n_cols != T1D_P_NCOLS) return fail(T1D_E_INVALID, "t1d_split_tables: n_cols must be T1D_P_NCOLS (45)");
     if (n_sub < 2 || n_sub > 8 || (n_sub & 1)) return fail(T1D_E_INVALID, "t1d_split_tables: n_sub must be 2, 4, 6 or 8");
-    if (out_len < kPropRows(n_sub) + 8) return fail(T1D_E_INVALID, "t1d_split_tables: out_len < 14 n_sub + 29");
+    if (out_len < kPropRows(n_sub) + 12) return fail(T1D_E_INVALID, "t1d_split_tables: out_len < 28 n_sub + 33");
     split_tables_row(patient_row, n_sub, out);
     return T1D_OK;
 }
@@ -203,21 +200,15 @@ extern "C" int t1d_split_tables(const double* patient_row, int n_cols, int n_sub
 // (re)build the device tables of the split integrator for n_sub sub-steps per minute
 static int ensure_split(t1d_ctx* c, int ng)
 {
+    static_assert(DP_X2WB0 == DP_X2E + 11 && DP_X2E2 == DP_X2E + 4 && DP_X2E0 == DP_X2E + 8, "x2 weight rows are consecutive");
     if (c->split_nsub == ng) return T1D_OK;
     T1D_HIP(hipDeviceSynchronize());                     // kernels in flight may still be reading the old tables
     const int rows = kPropRows(ng), npp = c->np_pad;
-    std::vector<double> prop((size_t)rows * npp, 0.0), one((size_t)rows + 8);
+    std::vector<double> prop((size_t)rows * npp, 0.0), one((size_t)rows + 12);
     for (int j = 0; j < c->np; ++j) {
         split_tables_row(c->ptab.data() + (size_t)j * T1D_P_NCOLS, ng, one.data());
         for (int k = 0; k < rows; ++k) prop[(size_t)k * npp + j] = one[k];
-        c->dpar[(size_t)DP_X2E * kMaxPatients + j] = one[rows];
-        c->dpar[(size_t)DP_X2WA * kMaxPatients + j] = one[rows + 1];
-        c->dpar[(size_t)DP_X2WM * kMaxPatients + j] = one[rows + 2];
-        c->dpar[(size_t)DP_X2WB * kMaxPatients + j] = one[rows + 3];
-        c->dpar[(size_t)DP_X2E2 * kMaxPatients + j] = one[rows + 4];
-        c->dpar[(size_t)DP_X2WA2 * kMaxPatients + j] = one[rows + 5];
-        c->dpar[(size_t)DP_X2WM2 * kMaxPatients + j] = one[rows + 6];
-        c->dpar[(size_t)DP_X2WB2 * kMaxPatients + j] = one[rows + 7];
+        for (int k = 0; k < 12; ++k) c->dpar[(size_t)(DP_X2E + k) * kMaxPatients + j] = one[rows + k];   // DP_X2E .. DP_X2WB0
     }
     std::vector<float> propf(prop.begin(), prop.end()), dpf(c->dpar.begin(), c->dpar.end());
     (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); c->d_prop64 = nullptr; c->d_prop32 = nullptr;
@@ -239,7 +230,7 @@ static bool use_split(const t1d_ctx* c, int n_sub)
 }
 
 #if T1D_S1_TRACE
-extern "C" int t1d_debug_trace(t1d_ctx* c, long long* out) { return hipMemcpy(out, c->d_trace, 96 * 4 * 64 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+extern "C" int t1d_debug_trace(t1d_ctx* c, long long* out) { return hipMemcpy(out, c->d_trace, 128 * 4 * 64 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 #endif
 extern "C" int t1d_abi_version(void) { return T1D_ABI_VERSION; }
 extern "C" const char* t1d_last_error(void) { return g_err.c_str(); }
@@ -318,8 +309,8 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
         if (e == hipSuccess) e = up((void**)&c->d_minv64, minv.data(), minv.size() * 8);
         if (e == hipSuccess) e = up((void**)&c->d_minv32, minvf.data(), minvf.size() * 4);
 #if T1D_S1_TRACE
-        if (e == hipSuccess) e = hipMalloc((void**)&c->d_trace, 96 * 4 * 64 * sizeof(long long));
-        if (e == hipSuccess) e = hipMemset(c->d_trace, 0, 96 * 4 * 64 * sizeof(long long));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_trace, 128 * 4 * 64 * sizeof(long long));
+        if (e == hipSuccess) e = hipMemset(c->d_trace, 0, 128 * 4 * 64 * sizeof(long long));
 #endif
         if (e == hipSuccess) e = hipMalloc((void**)&c->d_status, sizeof(int));
         if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(int));
@@ -340,66 +331,24 @@ extern "C" int t1d_ctx_create(int hip_device, const double* ptab, int n_patients
 extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
 {
     if (!c || !name) return fail(T1D_E_INVALID, "t1d_ctx_set_option: NULL argument");
-    if (std::strcmp(name, "math") == 0) {
-        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: math must be 0 or 1");
-        c->math = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "params_mode") == 0) {
-        if (value < -1 || value > 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: params_mode must be -1, 0 or 1");
-        c->params_mode = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "split_refill") == 0) {
-        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: split_refill must be 0 or 1");
-        c->split_refill = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "pipe_stagger") == 0) {
-        if (value < 0 || value > 64) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipe_stagger out of range");
-        c->pipe_stagger = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "defer_min_chunks") == 0) {
-        if (value < 0 || value > 65535) return fail(T1D_E_INVALID, "t1d_ctx_set_option: defer_min_chunks out of range");
-        c->defer_min_chunks = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "defer_min_envs") == 0) {
-        if (value < 0) return fail(T1D_E_INVALID, "t1d_ctx_set_option: defer_min_envs must be >= 0");
-        c->defer_min_envs = value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "pipe_blocks") == 0) {
-        if (value < 0 || value > 65535) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipe_blocks out of range");
-        c->pipe_blocks = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "pipeline") == 0) {
-        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: pipeline must be 0 or 1");
-        c->pipeline = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "adaptive_gut") == 0) {
-        if (value < 0 || value > 3) return fail(T1D_E_INVALID, "t1d_ctx_set_option: adaptive_gut must be 0, 1, 2 or 3");
-        c->adaptive_gut = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "single_minute_kernel") == 0) {
-        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: single_minute_kernel must be 0 or 1");
-        c->single_minute_kernel = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "integrator") == 0) {
-        if (value < -1 || value > 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: integrator must be -1 (auto), 0 (rk4) or 1 (split)");
-        c->integrator = (int)value;
-        return T1D_OK;
-    }
-    if (std::strcmp(name, "scalar_params") == 0) {
-        if (value != 0 && value != 1) return fail(T1D_E_INVALID, "t1d_ctx_set_option: scalar_params must be 0 or 1");
-        c->scalar_params = (int)value;
-        return T1D_OK;
-    }
+    struct Opt { const char* name; int t1d_ctx::*field; int64_t lo, hi; };
+    static const Opt opts[] = {
+        {"math", &t1d_ctx::math, 0, 1},
+        {"split_refill", &t1d_ctx::split_refill, 0, 1},
+        {"defer_min_chunks", &t1d_ctx::defer_min_chunks, 0, 65535},
+        {"dreg_max_chunks", &t1d_ctx::dreg_max_chunks, 0, 65535},
+        {"s1_blocks", &t1d_ctx::s1_blocks, 0, 65535},
+        {"adaptive_gut", &t1d_ctx::adaptive_gut, 0, 3},
+        {"single_minute_kernel", &t1d_ctx::single_minute_kernel, 0, 1},
+        {"integrator", &t1d_ctx::integrator, -1, 1},
+    };
+    for (const Opt& o : opts)
+        if (std::strcmp(name, o.name) == 0) {
+            if (value < o.lo || value > o.hi)
+                return fail(T1D_E_INVALID, std::string("t1d_ctx_set_option: ") + name + " must be in [" + std::to_string(o.lo) + ", " + std::to_string(o.hi) + "]");
+            c->*(o.field) = (int)value;
+            return T1D_OK;
+        }
     return fail(T1D_E_INVALID, std::string("t1d_ctx_set_option: unknown option ") + name);
 }
 
@@ -409,7 +358,7 @@ extern "C" int t1d_ctx_destroy(t1d_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_par64); (void)hipFree(c->d_par32); (void)hipFree(c->d_x0);
     (void)hipFree(c->d_minv64); (void)hipFree(c->d_minv32); (void)hipFree(c->d_status);
-    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); (void)hipFree(c->d_trace); (void)hipFree(c->d_defer);
+    (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); (void)hipFree(c->d_trace);
     delete c;
     return T1D_OK;
 }
@@ -432,6 +381,10 @@ static int check_batch(const char* who, const t1d_ctx* c, const t1d_batch* b, bo
         return fail(T1D_E_INVALID, std::string(who) + ": n_meals > 0 but meal table pointer is NULL");
     if (b->n_normals < 0) return fail(T1D_E_INVALID, std::string(who) + ": n_normals < 0");
     if (b->n_normals > 0 && !b->normals) return fail(T1D_E_INVALID, std::string(who) + ": n_normals > 0 but normals is NULL");
+    const int known = T1D_BATCH_NO_PUMP | T1D_BATCH_NO_REFILL_DUE | (T1D_AB_FLAGS ? 0xf00 : 0);
+    if (b->flags & ~known) return fail(T1D_E_INVALID, std::string(who) + ": unknown bit in batch.flags");
+    // a ctx is bound to one device: every entry point that takes one launches (and allocates) there
+    if (hipSetDevice(c->device) != hipSuccess) return fail(T1D_E_HIP, std::string(who) + ": hipSetDevice failed");
     return T1D_OK;
 }
 
@@ -453,14 +406,13 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.x0tab = c->d_x0;
     a.minv = sizeof(T) == 8 ? (const T*)c->d_minv64 : (const T*)c->d_minv32;
     a.status = c->d_status; a.trace = c->d_trace;
-    a.dcnt = c->d_defer; a.dseg = c->d_defer ? c->d_defer + c->defer_tiles : nullptr;
     a.sen.pacf = (T)c->sensor[0]; a.sen.gamma = (T)c->sensor[1]; a.sen.lambda = (T)c->sensor[2];
     a.sen.delta = (T)c->sensor[3]; a.sen.xi = (T)c->sensor[4]; a.sen.st = (int)c->sensor[5];
     a.sen.vmin = (T)c->sensor[6]; a.sen.vmax = (T)c->sensor[7];
     a.pump.min_bolus = (T)c->pump[0]; a.pump.max_bolus = (T)c->pump[1]; a.pump.inc_bolus = (T)c->pump[2];
     a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
     a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
-    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags; a.stagger = c->pipe_stagger;
+    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags;
     a.prop = sizeof(T) == 8 ? (const T*)c->d_prop64 : (const T*)c->d_prop32;
     a.prop_rows = c->split_nsub ? kPropRows(c->split_nsub) : 0; a.np_pad = c->np_pad;
     return a;
@@ -491,6 +443,15 @@ static hipError_t allow_lds(t1d_ctx* c, const void* fn, size_t bytes)
     return e;
 }
 
+// Which generic kernel variant a call takes (t1d_kernels.hpp): reference arithmetic, fast classical RK4, split at
+// level 1, split with per-minute step sizes in place.
+static int pick_variant(const t1d_ctx* c, bool split)
+{
+    if (c->math == 0) return 0;
+    if (!split) return 3;
+    return c->adaptive_gut ? 7 : 4;
+}
+
 extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, void* stream)
 {
     int rc = check_batch("t1d_step", c, b, true);
@@ -498,24 +459,18 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, "t1d_step: minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, "t1d_step: n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    // measured at 1 Mi envs, fp64: VGPR parameters + sub-system-wise RK4 cost ~75 us + 78 us/minute, the LDS-
-    // parameter kernel ~55 us + 93 us/minute: equal at one minute per launch, VGPR form ahead beyond
-    const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
     if (c->integrator == 1 && !use_split(c, n_sub))
         return fail(T1D_E_INVALID, "t1d_step: the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
-    const bool split = use_split(c, n_sub) && !c->pipeline;
+    const bool split = use_split(c, n_sub);
+    const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
     size_t dyn = 0;
     if (split) {
         rc = ensure_split(c, n_sub);
         if (rc) return rc;
-        dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
+        dyn = (size_t)kPropRows(n_sub) * c->np_pad * esz;
         if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_step: split tables exceed 64 KiB of LDS (n_patients x n_sub too large); use integrator 0");
     }
-    const int variant = c->math == 0 ? 0 : (split ? (c->adaptive_gut ? ((pmode && b->dtype == T1D_F32) ? 6 : 7) : (pmode ? 4 : 5)) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
-    // (the adaptive scheme always takes its parameters from LDS: with them in VGPRs as well it spills)
-#define T1D_LAUNCH_STEP(V, TT) hipLaunchKernelGGL((step_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
-#define T1D_LAUNCH_PIPE(V, TT) hipLaunchKernelGGL((step_pipe_kernel<V, TT>), pgrid, dim3(kBlock), 0, s, make_args<TT>(c, b, minutes, n_sub))
-    const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
+    const int variant = pick_variant(c, split);
     const char* xb = (const char*)b->x;
     const size_t rowb = (size_t)b->n * esz;
     const bool packed = (const char*)b->planned == xb + 13 * rowb && (const char*)b->last_qsto == xb + 14 * rowb &&
@@ -524,16 +479,6 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
                         b->next_meal && (const char*)b->meta == (const char*)b->t + (size_t)b->n * 4 &&
                         (const char*)b->next_meal == (const char*)b->t + (size_t)b->n * 8 &&
                         (size_t)kPackedRows * rowb < ((size_t)1 << 32);
-    if (c->pipeline && (variant >= 1 && variant <= 3) && packed && b->n % kBlock == 0) {
-        // persistent grid: as many blocks as stay resident at T1D_WAVES waves per SIMD (4 SIMDs x waves / 4 waves per block)
-        const unsigned resident = c->pipe_blocks > 0 ? (unsigned)c->pipe_blocks : (unsigned)c->n_cu * T1D_WAVES;
-        const unsigned ntiles = grid_for(b->n).x;
-        const dim3 pgrid(ntiles < resident ? ntiles : resident);
-        if (b->dtype == T1D_F64) { if (variant == 1) T1D_LAUNCH_PIPE(1, double); else if (variant == 2) T1D_LAUNCH_PIPE(2, double); else T1D_LAUNCH_PIPE(3, double); }
-        else { if (variant == 1) T1D_LAUNCH_PIPE(1, float); else if (variant == 2) T1D_LAUNCH_PIPE(2, float); else T1D_LAUNCH_PIPE(3, float); }
-        T1D_HIP(hipGetLastError());
-        return T1D_OK;
-    }
     // At most one CGM sample per launch (minutes <= sample_time): the noise-block refill runs as its own
     // kernel ahead of a step kernel compiled without it, unless the caller vouches that none is due.
     const bool split_refill = variant != 0 && c->split_refill && minutes <= (int)c->sensor[5];
@@ -541,97 +486,57 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         if (b->dtype == T1D_F64) hipLaunchKernelGGL(refill_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s, make_args<double>(c, b, minutes, n_sub));
         else hipLaunchKernelGGL(refill_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
     }
-    // one simulated minute per launch with the split integrator: the persistent early-store kernel
-    if (split_refill && split && minutes == 1 && c->single_minute_kernel && packed && !(b->flags & 0x600)) {
+    // one simulated minute per launch with the split integrator: the persistent early-store kernels
+    if (split_refill && split && minutes == 1 && c->single_minute_kernel && packed && !(T1D_AB_FLAGS && (b->flags & 0x600))) {
         const int stride = c->np <= 32 ? 32 : 64;
-        const size_t esz1 = b->dtype == T1D_F64 ? 8 : 4;
-        const size_t dyn1 = (size_t)(DP_COUNT + kPropRows(n_sub)) * stride * esz1;
-        if (dyn1 <= 65536) {
+        const size_t dyn1 = (size_t)(DP_COUNT + kPropRows(n_sub)) * stride * esz;
+        if (dyn1 + 512 <= (size_t)c->lds_per_block) {
             const int nchunks = (int)((b->n + 63) / 64);
-            int blocks = c->pipe_blocks > 0 ? c->pipe_blocks : c->n_cu;       // one workgroup of 4 x T1D_S1_WAVES waves per CU
+            int blocks = c->s1_blocks > 0 ? c->s1_blocks : c->n_cu;           // one workgroup of 4 x T1D_S1_WAVES waves per CU
             if (blocks > nchunks) blocks = nchunks;
-            const bool reg = pmode != 0 && !c->adaptive_gut;
             const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
-            const bool adapt = c->adaptive_gut != 0;
-            // adaptive scheme: refinement deferred to the end of the launch (step1d_kernel) where the list of the
-            // CU's envs fits next to the tables; adaptive_gut = 2 asks for the in-place form
+            const bool tiered = c->adaptive_gut != 0;
+            // per-minute step sizes: lanes of levels 1 and 2 set aside and integrated together at the end of the launch
+            // (step1d_kernel) where level 0 exists (n_sub divisible by 4) and the two lists of the CU's envs fit next to
+            // the tables; adaptive_gut = 2 asks for the in-place form, 3 for the deferred form at any batch size
             const int per_block = (nchunks + blocks - 1) / blocks;
-            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(int);
-            // (deferred vs in place: 1 024 envs 12.8 vs 14.0 us, 16 384 envs 14.8 vs 15.4 us, 65 536 envs 16.2 vs 17.3 us,
-            // 131 072 envs 21 vs 26 us, 1 Mi envs 87 vs 117 us; short launches with VGPR parameters in the deferred pass too)
-            const bool defer = adapt && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) && stride == 32 &&
-                               dyn1d + 512 <= (size_t)c->lds_per_block;
-#define T1D_LAUNCH_S1(R, TT, ST, EX, AD) hipLaunchKernelGGL((step1_kernel<R, TT, ST, EX, AD>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks)
-#define T1D_LAUNCH_S1D_(R, TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<R, TT, 32, EX, DR>, dyn1d)); \
-        hipLaunchKernelGGL((step1d_kernel<R, TT, 32, EX, DR>), dim3(blocks), dim3(kS1Threads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
-#define T1D_LAUNCH_S1D(R, TT, EX) do { if (R && per_block < 32) T1D_LAUNCH_S1D_(R, TT, EX, R); else T1D_LAUNCH_S1D_(R, TT, EX, false); } while (0)
-#define T1D_S1_BY_EXTRA(R, TT, ST) do { if (adapt) { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, true); else T1D_LAUNCH_S1(R, TT, ST, false, true); } \
-                                        else { if (extra) T1D_LAUNCH_S1(R, TT, ST, true, false); else T1D_LAUNCH_S1(R, TT, ST, false, false); } } while (0)
-#define T1D_S1D_BY_EXTRA(R, TT) do { if (extra) T1D_LAUNCH_S1D(R, TT, true); else T1D_LAUNCH_S1D(R, TT, false); } while (0)
+            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * 2 * sizeof(int);
+            const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
+                               stride == 32 && !(n_sub & 3) && dyn1d + 512 <= (size_t)c->lds_per_block;
+#define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
+        hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+#define T1D_LAUNCH_S1D(TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR>, dyn1d)); \
+        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR>), dim3(blocks), dim3(kS1Threads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+#define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \
+                               else { if (extra) T1D_LAUNCH_S1(TT, ST, true, false); else T1D_LAUNCH_S1(TT, ST, false, false); } } while (0)
+#define T1D_S1D_BY(TT) do { const bool dreg = per_block < c->dreg_max_chunks; \
+                            if (extra) { if (dreg) T1D_LAUNCH_S1D(TT, true, true); else T1D_LAUNCH_S1D(TT, true, false); } \
+                            else { if (dreg) T1D_LAUNCH_S1D(TT, false, true); else T1D_LAUNCH_S1D(TT, false, false); } } while (0)
             if (defer) {
-                const bool regd = pmode != 0;              // the main pass has no refinement code: its parameters fit in VGPRs
-                if (b->dtype == T1D_F64) { if (regd) T1D_S1D_BY_EXTRA(true, double); else T1D_S1D_BY_EXTRA(false, double); }
-                else { if (regd) T1D_S1D_BY_EXTRA(true, float); else T1D_S1D_BY_EXTRA(false, float); }
+                if (b->dtype == T1D_F64) T1D_S1D_BY(double); else T1D_S1D_BY(float);
             } else if (b->dtype == T1D_F64) {
-                if (stride == 32) { if (reg) T1D_S1_BY_EXTRA(true, double, 32); else T1D_S1_BY_EXTRA(false, double, 32); }
-                else { if (reg) T1D_S1_BY_EXTRA(true, double, 64); else T1D_S1_BY_EXTRA(false, double, 64); }
+                if (stride == 32) T1D_S1_BY(double, 32); else T1D_S1_BY(double, 64);
             } else {
-                if (stride == 32) { if (reg) T1D_S1_BY_EXTRA(true, float, 32); else T1D_S1_BY_EXTRA(false, float, 32); }
-                else { if (reg) T1D_S1_BY_EXTRA(true, float, 64); else T1D_S1_BY_EXTRA(false, float, 64); }
+                if (stride == 32) T1D_S1_BY(float, 32); else T1D_S1_BY(float, 64);
             }
-#undef T1D_S1D_BY_EXTRA
-#undef T1D_S1_BY_EXTRA
+#undef T1D_S1D_BY
+#undef T1D_S1_BY
 #undef T1D_LAUNCH_S1D
-#undef T1D_LAUNCH_S1D_
 #undef T1D_LAUNCH_S1
             T1D_HIP(hipGetLastError());
             return T1D_OK;
         }
     }
-    // adaptive scheme, any minutes per launch, refill-free, large batch: fixed-step launch that sets flagged envs aside
-    // (stepa_kernel) + a launch that redoes those with the in-place rule (stepr_kernel)
-    if (split_refill && split && (variant == 6 || variant == 7) &&
-        (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && b->n >= c->defer_min_envs))) {
-        const int64_t ntiles = (b->n + kBlock - 1) / kBlock;
-        if (c->defer_tiles < ntiles) {
-            (void)hipFree(c->d_defer); c->d_defer = nullptr; c->defer_tiles = 0;
-            T1D_HIP(hipMalloc((void**)&c->d_defer, (size_t)ntiles * (1 + kBlock) * sizeof(int)));
-            c->defer_tiles = ntiles;
-        }
-        const size_t dynr = dyn;
-        const dim3 gridr((unsigned)((ntiles + kDeferGroup * (kBlock / 64) - 1) / (kDeferGroup * (kBlock / 64))));
-        if (b->dtype == T1D_F64) {
-            hipLaunchKernelGGL(stepa_kernel<double>, grid_for(b->n), dim3(kBlock), dyn, s, make_args<double>(c, b, minutes, n_sub));
-            hipLaunchKernelGGL(stepr_kernel<double>, gridr, dim3(kBlock), dynr, s, make_args<double>(c, b, minutes, n_sub), (int)ntiles);
-        } else {
-            hipLaunchKernelGGL(stepa_kernel<float>, grid_for(b->n), dim3(kBlock), dyn, s, make_args<float>(c, b, minutes, n_sub));
-            hipLaunchKernelGGL(stepr_kernel<float>, gridr, dim3(kBlock), dynr, s, make_args<float>(c, b, minutes, n_sub), (int)ntiles);
-        }
-        T1D_HIP(hipGetLastError());
-        return T1D_OK;
-    }
-#define T1D_LAUNCH_FAST(V, TT) hipLaunchKernelGGL((step_kernel<V, TT, false>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
-#define T1D_BY_VARIANT(L, TT) do { switch (variant) { case 0: L(0, TT); break; case 1: L(1, TT); break; case 2: L(2, TT); break; \
-                                                      case 3: L(3, TT); break; case 4: L(4, TT); break; case 5: L(5, TT); break; \
-                                                      default: L(7, TT); break; } } while (0)
-    if (split_refill) {          // variant != 0 here
-        if (b->dtype == T1D_F64) { switch (variant) { case 1: T1D_LAUNCH_FAST(1, double); break; case 2: T1D_LAUNCH_FAST(2, double); break; case 3: T1D_LAUNCH_FAST(3, double); break;
-                                                      case 4: T1D_LAUNCH_FAST(4, double); break; case 5: T1D_LAUNCH_FAST(5, double); break;
-                                                      default: T1D_LAUNCH_FAST(7, double); break; } }
-        else { switch (variant) { case 1: T1D_LAUNCH_FAST(1, float); break; case 2: T1D_LAUNCH_FAST(2, float); break; case 3: T1D_LAUNCH_FAST(3, float); break;
-                                  case 4: T1D_LAUNCH_FAST(4, float); break; case 5: T1D_LAUNCH_FAST(5, float); break;
-                                  case 6: T1D_LAUNCH_FAST(6, float); break; default: T1D_LAUNCH_FAST(7, float); break; } }
-    } else if (b->dtype == T1D_F64) {
-        T1D_BY_VARIANT(T1D_LAUNCH_STEP, double);
-    } else if (variant == 6) {           // fp32 only: with the parameters in VGPRs the adaptive scheme fits there (fp64 spills)
-        T1D_LAUNCH_STEP(6, float);
+#define T1D_LAUNCH_STEP(V, TT, RF) hipLaunchKernelGGL((step_kernel<V, TT, RF>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
+#define T1D_BY_VARIANT(TT, RF) do { switch (variant) { case 0: T1D_LAUNCH_STEP(0, TT, RF); break; case 3: T1D_LAUNCH_STEP(3, TT, RF); break; \
+                                                       case 4: T1D_LAUNCH_STEP(4, TT, RF); break; default: T1D_LAUNCH_STEP(7, TT, RF); break; } } while (0)
+    if (split_refill) {          // the refill ran ahead (or none is due): the kernel compiled without it
+        if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, false); else T1D_BY_VARIANT(float, false);
     } else {
-        T1D_BY_VARIANT(T1D_LAUNCH_STEP, float);
+        if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, true); else T1D_BY_VARIANT(float, true);
     }
-#undef T1D_LAUNCH_FAST
 #undef T1D_BY_VARIANT
 #undef T1D_LAUNCH_STEP
-#undef T1D_LAUNCH_PIPE
     T1D_HIP(hipGetLastError());
     return T1D_OK;
 }
@@ -675,7 +580,6 @@ static int launch_rollout(const char* who, t1d_ctx* c, const t1d_batch* b, int n
     if (minutes < 1 || minutes > 100000) return fail(T1D_E_INVALID, std::string(who) + ": minutes out of range");
     if (n_sub < 1 || n_sub > 4096) return fail(T1D_E_INVALID, std::string(who) + ": n_sub out of range");
     hipStream_t s = (hipStream_t)stream;
-    const int pmode = c->params_mode >= 0 ? c->params_mode : 1;
     if (c->integrator == 1 && !use_split(c, n_sub))
         return fail(T1D_E_INVALID, std::string(who) + ": the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
     const bool split = use_split(c, n_sub);
@@ -686,13 +590,11 @@ static int launch_rollout(const char* who, t1d_ctx* c, const t1d_batch* b, int n
         dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
         if (dyn > 65536) return fail(T1D_E_INVALID, std::string(who) + ": split tables exceed 64 KiB of LDS; use integrator 0");
     }
-    const int variant = c->math == 0 ? 0 : (split ? (c->adaptive_gut ? 7 : (pmode ? 4 : 5)) : (((b->flags & T1D_BATCH_WAVE_UNIFORM) && c->scalar_params) ? 2 : (pmode ? 3 : 1)));
+    const int variant = pick_variant(c, split);
 #define T1D_LAUNCH_ROLL(V, TT, MK) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, \
                                                       make_args<TT>(c, b, minutes, n_sub), MK())
-#define T1D_BY_VARIANT(TT, MK) do { switch (variant) { case 0: T1D_LAUNCH_ROLL(0, TT, MK); break; case 1: T1D_LAUNCH_ROLL(1, TT, MK); break; \
-                                                       case 2: T1D_LAUNCH_ROLL(2, TT, MK); break; case 3: T1D_LAUNCH_ROLL(3, TT, MK); break; \
-                                                       case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; case 5: T1D_LAUNCH_ROLL(5, TT, MK); break; \
-                                                       default: T1D_LAUNCH_ROLL(7, TT, MK); break; } } while (0)
+#define T1D_BY_VARIANT(TT, MK) do { switch (variant) { case 0: T1D_LAUNCH_ROLL(0, TT, MK); break; case 3: T1D_LAUNCH_ROLL(3, TT, MK); break; \
+                                                       case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; default: T1D_LAUNCH_ROLL(7, TT, MK); break; } } while (0)
     if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, mk64);
     else T1D_BY_VARIANT(float, mk32);
 #undef T1D_BY_VARIANT
@@ -777,6 +679,7 @@ extern "C" int t1d_philox_normals(t1d_ctx* c, uint64_t seed, int64_t env_offset,
                                   int32_t draw0, int32_t n_draws, double* out, void* stream)
 {
     if (!c || !out || n < 1 || n_draws < 1 || draw0 < -3) return fail(T1D_E_INVALID, "t1d_philox_normals: bad argument");
+    T1D_HIP(hipSetDevice(c->device));
     hipLaunchKernelGGL(philox_normals_kernel, grid_for(n), dim3(kBlock), 0, (hipStream_t)stream, seed, env_offset, n,
                        episode, draw0, n_draws, out);
     T1D_HIP(hipGetLastError());
@@ -786,6 +689,7 @@ extern "C" int t1d_philox_normals(t1d_ctx* c, uint64_t seed, int64_t env_offset,
 extern "C" int t1d_sync(t1d_ctx* c, void* stream, int32_t* status)
 {
     if (!c) return fail(T1D_E_INVALID, "t1d_sync: ctx is NULL");
+    T1D_HIP(hipSetDevice(c->device));
     T1D_HIP(hipStreamSynchronize((hipStream_t)stream));
     int st = 0;
     T1D_HIP(hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));

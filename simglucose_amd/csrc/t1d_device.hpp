@@ -5,12 +5,10 @@
 // sees one coalesced read and one coalesced write of the struct-of-arrays state per launch.
 //
 // Per-patient parameters reach the RHS in one of two ways (template policy):
-//   ParsLds     the table is staged in LDS (param-major: lanes holding different patients hit
-//               different banks, equal patients broadcast) and each RHS evaluation re-reads what it
-//               needs, so no parameter occupies a VGPR across the RK4 loop;
-//   ParsScalar  every lane of the wave simulates the same patient (the host lays envs out in
-//               patient-homogeneous runs of 64): the row is fetched with scalar loads and lives in
-//               SGPRs -- zero VGPRs, zero LDS traffic.
+//   ParsLds / ParsLdsS  the table is staged in LDS (param-major: lanes holding different patients hit
+//               different banks, equal patients broadcast) and each evaluation re-reads what it
+//               needs, so no parameter occupies a VGPR across the sub-step loops;
+//   ParsReg     gathered once per lane into VGPRs (no LDS round trip in the dependent chains).
 //
 // Reference behaviour restated here (paths relative to the reference checkout):
 //   rhs()            simglucose/patient/t1dpatient.py:119-208   T1DPatient.model
@@ -32,12 +30,13 @@ enum DevPar : int {
     DP_K1, DP_K2, DP_VM0, DP_VMX, DP_KM0, DP_M24 /*m2+m4*/, DP_M1, DP_KA1, DP_KA2, DP_VI, DP_P2U,
     DP_IB, DP_KI, DP_M130 /*m1+m30*/, DP_M2, DP_KA1KD /*ka1+kd*/, DP_KD, DP_KSC, DP_INSC /*6000/BW*/,
     DP_VG, DP_IVI /*1/Vi*/, DP_IVG /*1/Vg*/, DP_DK /*kmax-kmin*/,
-    // split integrator only; the four x2 weights depend on n_sub and are rewritten when it changes
+    // split integrator only; the x2 weights depend on n_sub and are rewritten when it changes: gut step of level 1
+    // (h = 1/n_sub), of level 2 (h/4) and of level 0 (2 h)
     DP_CF /*f/BW*/, DP_X2E /*exp(-kabs h)*/, DP_X2WA, DP_X2WM, DP_X2WB,
-    DP_X2E2 /*the same four for h/2: refined gut steps of the adaptive split scheme*/, DP_X2WA2, DP_X2WM2, DP_X2WB2, DP_COUNT
+    DP_X2E2, DP_X2WA2, DP_X2WM2, DP_X2WB2, DP_X2E0, DP_X2WA0, DP_X2WM0, DP_X2WB0, DP_COUNT
 };
 constexpr int DP_RK4_COUNT = DP_CF;    // rows the classical-RK4 kernels stage
-constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 47 x 64 x 8 B = 23.5 KiB
+constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 51 x 64 x 8 B = 25.5 KiB
 constexpr int kBlock = 256;
 
 // parameters re-read from LDS at every use; refresh() makes the base opaque so the compiler
@@ -56,9 +55,10 @@ __device__ constexpr int kRhsPars[] = {DP_KMAX, DP_DK, DP_KABS, DP_RATC, DP_KP1,
                                        DP_K1, DP_K2, DP_VM0, DP_VMX, DP_KM0, DP_M24, DP_M1, DP_KA1, DP_KA2, DP_IVI, DP_P2U,
                                        DP_IB, DP_KI, DP_M130, DP_M2, DP_KA1KD, DP_KD, DP_KSC};
 // the parameters the split integrator reads inside its loops
+// the parameters the split integrator reads inside its loops (the x2 weights by level: kSplitW below)
 __device__ constexpr int kSplitPars[] = {DP_KMAX, DP_DK, DP_RATC, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2, DP_K1, DP_K2,
-                                         DP_VM0, DP_VMX, DP_KM0, DP_KSC, DP_CF, DP_X2E, DP_X2WA, DP_X2WM, DP_X2WB};
-__device__ constexpr int kAdaptPars[] = {DP_X2E2, DP_X2WA2, DP_X2WM2, DP_X2WB2};      // read by refined lanes only
+                                         DP_VM0, DP_VMX, DP_KM0, DP_KSC, DP_CF};
+__host__ __device__ constexpr int kSplitW(int level) { return level == 0 ? DP_X2E0 : (level == 1 ? DP_X2E : DP_X2E2); }
 // parameters gathered once per lane from the (L2-resident) table and held in VGPRs for the launch
 template <typename T> struct ParsReg {
     static constexpr bool kSplitRk4 = true;    // measured: 75 us/minute split vs 79 unsplit, and far fewer spills around the loop
@@ -82,21 +82,6 @@ template <typename T> struct ParsReg {
         for (int k = 0; k < DP_COUNT; ++k) v[k] = tab[k * kMaxPatients + pid];
     }
 };
-// parameters of a wave-uniform patient, fetched once with scalar loads (SGPR resident)
-template <typename T> struct ParsScalar {
-    static constexpr bool kSplitRk4 = true;
-    T v[DP_COUNT];
-    __device__ __forceinline__ T operator()(int idx) const { return v[idx]; }
-    __device__ __forceinline__ void refresh() {}
-    __device__ __forceinline__ void pin() {}
-    __device__ __forceinline__ void pin_split() {}
-    __device__ __forceinline__ void load(const T* __restrict__ tab, int np, int pid_uniform)
-    {
-#pragma unroll
-        for (int k = 0; k < DP_COUNT; ++k) v[k] = tab[k * np + pid_uniform];
-    }
-};
-
 // ---- per-minute inputs of the RHS, constant over the RK4 sub-steps (t1dpatient.py:110-111) ----
 template <typename T> struct MinuteIn {
     T d_mg;      // eaten CHO, mg/min                      (:121)
@@ -399,24 +384,32 @@ __device__ __forceinline__ void rk4_substeps_split(P& p, const MinuteIn<T>& u, T
 // ---- split integrator ------------------------------------------------------------------------------
 // The same model advanced part by part with what each part needs (oracle: t1d_o_split_minute):
 //   insulin  (x5, x9, x10, x11, x6, x7, x8) is linear with the minute's constant infusion (t1dpatient.py:
-//            176-198): exact propagator, s(tau) = Phi(tau) [s; u; 1], tau = k/ng.  The host stores the
-//            structurally non-zero entries of Phi only (PropRows below); the table is staged in LDS.
-//   gut      x0, x1 (:133-145): classical RK4, ng steps of h = 1/ng, with Q = int kgut x1 by the same
-//            quadrature; x2 (:148), whose rate kabs is the fastest of the model, in exponential form
-//            x2' = E x2 + wa F1 + wm (F2 + F3)/2 + wb F4;  R += (x2 - x2') + dQ = mass absorbed so far.
-//   glucose  (x3, x4, x12) (:151-173,201-202): classical RK4, ns = ng/2 steps, on z3 = x3 - c R with
-//            c = f/BW: the rate of appearance enters through x3 = z3 + c R(tau) at the stage times, where
-//            X = x6 and XL = x8 come from the propagator.
-// Accuracy against a tight solve equals RK4(n_sub = ng) on all 13 states (both are limited by the
-// gastric-emptying tanh); arithmetic is ~60 % of it, and far fewer values are alive at once.
+//            176-198): exact propagator, s(tau) = Phi(tau) [s; u; 1].  The host stores the structurally
+//            non-zero entries of Phi(k / (2 n_sub)), k = 1 .. 2 n_sub (PropRows below); the table is staged in LDS.
+//   gut      x0, x1 (:133-145): classical RK4, with Q = int kgut x1 by the same quadrature; x2 (:148), whose rate
+//            kabs is the fastest of the model, in exponential form x2' = E x2 + wa F1 + wm (F2 + F3)/2 + wb F4;
+//            R += (x2 - x2') + dQ = mass absorbed so far.
+//   glucose  (x3, x4, x12) (:151-173,201-202): classical RK4 on z3 = x3 - c R with c = f/BW: the rate of
+//            appearance enters through x3 = z3 + c R(tau) at the stage times, where X = x6 and XL = x8 come
+//            from the propagator.  A step that begins with x3 < 0 holds x3 (every stage of the reference's RHS
+//            returns dx3 = 0 there, :167); a step that takes x3 below zero ends at -1e-10, which is where scipy's
+//            step-size control leaves it (a fixed step would overshoot by up to ~0.1 mg/kg and keep that).
+// Step sizes per minute and env -- LEVEL -- from the state and the rates at the start of the minute (tier_level):
+//   0  gut n_sub/2 steps, glucose n_sub/4     calm minutes, ~95 % of the env-minutes of RandomScenario days
+//   1  gut n_sub steps,   glucose n_sub/2     (the fixed-step form of the scheme takes this one in every minute)
+//   2  gut 4 n_sub steps, glucose n_sub       an argument of the gastric-emptying tanh pair (:138-140) moves fast
+//      through its transition, a kink of the glucose sub-system (EGP floor :165, renal threshold :158-161,
+//      x3 = 0 :167) is about to be crossed, or the tissue compartment is fast (large insulin action)
+// Against a tight solve of 600 random env-days: max 1.7e-4 mg/dL (level 1 everywhere: 6.9e-3).
 //
-// Propagator rows, ng blocks of 14 then a tail of 21 (kPropRows(ng) = 14 ng + 21):
-//   block k = 1..ng at (k-1)*14:  x6(k/ng) <- [x6, x5, x9, x10, x11, u, 1],  x8(k/ng) <- [x8, x7, x5, x9, x10, x11, u]
-//   tail (tau = 1) at 14 ng:      x5 <- [x5, x9, x10, x11, u], x9 <- same, x10 <- [x10, u], x11 <- [x10, x11, u],
+// Propagator rows, 2 n_sub blocks of 14 then a tail of 21 (kPropRows(n_sub) = 28 n_sub + 21):
+//   block k = 1..2 n_sub at (k-1)*14, tau = k/(2 n_sub):
+//                                 x6(tau) <- [x6, x5, x9, x10, x11, u, 1],  x8(tau) <- [x8, x7, x5, x9, x10, x11, u]
+//   tail (tau = 1) at 28 n_sub:   x5 <- [x5, x9, x10, x11, u], x9 <- same, x10 <- [x10, u], x11 <- [x10, x11, u],
 //                                 x7 <- [x7, x5, x9, x10, x11, u]
-__host__ __device__ constexpr int kPropRows(int ng) { return 14 * ng + 21; }
+__host__ __device__ constexpr int kPropRows(int n_sub) { return 28 * n_sub + 21; }
 
-struct NoProp { static constexpr bool kSplit = false, kAdapt = false, kForce = false; };
+struct NoProp { static constexpr bool kSplit = false; };
 // compact LDS tables with a compile-time row stride (persistent single-minute kernel): every read is one
 // ds_read_b64 with an immediate offset
 template <typename T, int STRIDE> struct ParsLdsS {
@@ -427,26 +420,18 @@ template <typename T, int STRIDE> struct ParsLdsS {
     __device__ __forceinline__ void pin() {}
     __device__ __forceinline__ void pin_split() {}
 };
-// FORCE (with ADAPT): every lane takes the halved gut steps -- the deferred pass of step1d_kernel, whose lanes were
-// all flagged by the same rule beforehand
-template <typename T, int STRIDE, bool ADAPT = false, bool FORCE = false> struct PropLdsS {
-    static constexpr bool kSplit = true, kAdapt = ADAPT, kForce = ADAPT && FORCE;
+template <typename T, int STRIDE> struct PropLdsS {
+    static constexpr bool kSplit = true;
     const T* base; int pid;
     __device__ __forceinline__ T operator()(int r) const { return base[r * STRIDE + pid]; }
 };
 // table in LDS, [rows][stride] with the patient index fastest (different patients -> different banks)
-template <typename T, bool ADAPT = false> struct PropLds {
-    static constexpr bool kSplit = true, kAdapt = ADAPT, kForce = false;
+template <typename T> struct PropLds {
+    static constexpr bool kSplit = true;
     const T* base; int stride; int pid;
     __device__ __forceinline__ T operator()(int r) const { return base[r * stride + pid]; }
 };
 
-// ADAPT: in the minutes in which an argument of the gastric-emptying tanh pair moves fast through its transition
-// (|change over the minute| > 4, predicted from the rate at the start of the minute, while passing within 3 of
-// zero) a lane takes TWO gut steps of h/2 where the others take one of h.  That is where fixed steps lose their
-// accuracy (steep patients after large meals); it concerns < 1 % of the env-minutes of a RandomScenario day and
-// brings the error against a tight solve down to that of n_sub doubled everywhere.  The second half step runs
-// under the flagged lanes' exec mask and is skipped by waves that have none.
 // kgut(x0 + x1) * x1, the flux out of the stomach's liquid compartment                         (t1dpatient.py:126-145)
 template <typename T, typename P>
 __device__ __forceinline__ T kgut_flux(P& p, const MinuteIn<T>& u, T q0, T q1)
@@ -461,51 +446,91 @@ __device__ __forceinline__ T kgut_flux(P& p, const MinuteIn<T>& u, T q0, T q1)
     return kgut * q1;
 }
 
-// The refinement rule of the adaptive scheme, from the state at the start of the minute and F1 = kgut_flux there.
-template <typename T>
-__device__ __forceinline__ bool gut_refine_flag(const MinuteIn<T>& u, T g0, T g1, T F1)
+// d(z3, x4, x12)/dt at a stage of the glucose sub-system: y3 = z3 at the stage, cR = c R and cD = c R' there, X = x6,
+// XL = x8.  hold: the step began with x3 = x3hold < 0 and keeps it.  q4 (optional) = Vmt / (Km0 + x4).
+template <typename T, typename P>
+__device__ __forceinline__ void glucose_rhs(P& p, T y3, T y4, T y12, T cR, T cD, T X, T XL, bool hold, T x3hold,
+                                            T& d3, T& d4, T& d12, T* q4 = nullptr)
 {
-    const T dq = u.d_mg - F1;                                   // d(qsto)/dt at the start of the minute
-    const T q0 = g0 + g1;
-    const T A0 = T(0.5) * u.aa * (q0 - u.bD), dA = T(0.5) * u.aa * dq;      // u.aa, u.cc hold twice the slopes
-    const T C0 = T(0.5) * u.cc * (q0 - u.dD), dC = T(0.5) * u.cc * dq;
-    const T A1 = A0 + dA, C1 = C0 + dC;
-    const bool fa = fabs(dA) > T(4) && (A0 * A1 <= T(0) || t_min(fabs(A0), fabs(A1)) < T(3));
-    const bool fc = fabs(dC) > T(4) && (C0 * C1 <= T(0) || t_min(fabs(C0), fabs(C1)) < T(3));
-    return fa || fc;
+    p.refresh();
+    const T x3 = hold ? x3hold : y3 + cR;
+    const T egp = p(DP_KP1) - p(DP_KP2) * x3 - p(DP_KP3) * XL;                             // :153
+    const T et = p(DP_KE1) * t_max(x3 - p(DP_KE2), T(0));                                  // :158-161
+    const T k1x3 = p(DP_K1) * x3, k2x4 = p(DP_K2) * y4;
+    const T f3 = t_max(egp, T(0)) - p(DP_FSNC) - et - k1x3 + k2x4;                         // :165 without Rat
+    d3 = (x3 >= T(0)) ? f3 : -cD;                                                          // :167: dx3 = 0 <=> dz3 = -c R'
+    const T vmt = p(DP_VM0) + p(DP_VMX) * X;                                               // :169
+    const T q = fdiv_loop(vmt, p(DP_KM0) + y4);
+    const T f4 = -q * y4 + k1x3 - k2x4;                                                    // :171-172
+    d4 = (y4 >= T(0)) ? f4 : T(0);                                                         // :173
+    const T ksc = p(DP_KSC);
+    const T f12 = -ksc * y12 + ksc * x3;                                                   // :201
+    d12 = (y12 >= T(0)) ? f12 : T(0);                                                      // :202
+    if (q4) *q4 = q;
 }
 
-// HAVE_F1: the caller has evaluated kgut_flux at the start of the minute already (to take the refinement decision
-// outside) and hands it in as f1_pre.
-template <typename T, typename P, typename PR, bool HAVE_F1 = false>
-__device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int ng, T f1_pre = T(0))
+// The step-size rule (oracle: o_tier_level, same constants).  F1 = kgut_flux at the start of the minute, dx3 = dx3/dt
+// there (rate of appearance included), q4 = Vmt / (Km0 + x4) there.  Per lane, deterministic.
+template <typename T, typename P>
+__device__ __forceinline__ int tier_level(P& p, const MinuteIn<T>& u, const T (&x)[13], T F1, T dx3, T q4)
 {
-    constexpr bool ADAPT = PR::kAdapt;
-    constexpr bool FORCE = PR::kForce;
-    const int ns = ng >> 1;
-    const T h = T(1) / T(ng), hh = T(0.5) * h, h6 = h / T(6);
-    const T H = h + h, H6 = H / T(6);                 // glucose step; its half step is h
+    const T kNear = T(3), kMove = T(4), kCalm = T(1), kKink2 = T(1), kKink0 = T(2), kStiff0 = T(0.4), kStiff2 = T(1);
+    // gut: the arguments of the tanh pair and how far they move in this minute by the rate at its start
+    const T dq = u.d_mg - F1;                                   // d(qsto)/dt
+    const T q0 = x[0] + x[1];
+    const T A0 = T(0.5) * u.aa * (q0 - u.bD), dA = T(0.5) * u.aa * dq;      // u.aa, u.cc hold twice the slopes (0 without Dbar)
+    const T C0 = T(0.5) * u.cc * (q0 - u.dD), dC = T(0.5) * u.cc * dq;
+    const T A1 = A0 + dA, C1 = C0 + dC;
+    bool l2 = (fabs(dA) > kMove && (A0 * A1 <= T(0) || t_min(fabs(A0), fabs(A1)) < kNear)) ||
+              (fabs(dC) > kMove && (C0 * C1 <= T(0) || t_min(fabs(C0), fabs(C1)) < kNear));
+    bool calm = fabs(dA) < kCalm && fabs(dC) < kCalm;
+    // kinks of the glucose sub-system: g and where the rate at the start of the minute takes it
+    const T x3 = x[3];
+    const T xl_dot = -p(DP_KI) * (x[8] - x[7]);                                                 // :187
+    auto kink = [&](T g, T dg) {
+        const T g1 = g + dg, m = t_min(fabs(g), fabs(g1)), ad = fabs(dg);
+        const bool cross = g * g1 <= T(0);
+        l2 = l2 || cross || m < kKink2 * ad;
+        calm = calm && !(cross || m < kKink0 * ad);
+    };
+    kink(p(DP_KP1) - p(DP_KP2) * x3 - p(DP_KP3) * x[8], -p(DP_KP2) * dx3 - p(DP_KP3) * xl_dot);    // EGP floor, :153,165
+    kink(x3 - p(DP_KE2), dx3);                                                                   // renal threshold, :158
+    if (x3 >= T(0)) kink(x3, dx3); else calm = false;                                            // x3 = 0, :167; a held x3 is never level 0
+    const T lam4 = q4 + p(DP_K2);                               // rate of the tissue compartment under the current insulin action
+    calm = calm && !(lam4 > kStiff0);
+    l2 = l2 || lam4 > kStiff2;
+    return l2 ? 2 : (calm ? 0 : 1);
+}
+
+// One minute at a given LEVEL.  HAVE_F1 / HAVE_K1: the caller has evaluated kgut_flux / the first glucose stage at the
+// start of the minute already (for the step-size rule) and hands them in.
+template <int LEVEL, typename T, typename P, typename PR, bool HAVE_F1 = false, bool HAVE_K1 = false>
+__device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0),
+                                            T k3_pre = T(0), T k4_pre = T(0), T k12_pre = T(0))
+{
+    constexpr int GM = LEVEL == 2 ? 2 : 1;                      // gut steps per glucose half step
+    constexpr int SB = LEVEL == 0 ? 4 : (LEVEL == 1 ? 2 : 1);   // propagator blocks per glucose half step
+    constexpr int W = kSplitW(LEVEL);
+    const int nh = (2 * n_sub) / SB;                            // glucose half steps in the minute
+    const int ns = nh >> 1;
+    const T h = T(1) / T(nh);                                   // glucose half step
+    const T H = h + h, H6 = H / T(6);
+    const T gh = GM == 2 ? T(0.5) * h : h, ghh = T(0.5) * gh, gh6 = gh / T(6);      // gut step
     const T s5 = x[5], s6 = x[6], s7 = x[7], s8 = x[8], s9 = x[9], s10 = x[10], s11 = x[11], ui = u.ins;
     T g0 = x[0], g1 = x[1], x2 = x[2], R = T(0);      // R: mass that left x2 through kabs since the minute began
-    T z3 = x[3], x4 = x[4], x12 = x[12];
+    T x3a = x[3], x4 = x[4], x12 = x[12];             // x3 itself is carried from step to step: a held value stays bit for bit
     T cRa = T(0), cDa = p(DP_RATC) * x2, x6a = s6, x8a = s8;      // c R, c R', X, XL at the start of the glucose step
     auto kgutF = [&](T q0, T q1) -> T { return kgut_flux(p, u, q0, q1); };
     // One RK4 step of (x0, x1) + the exponential update of x2.  `pre(k)` / `post(k)` run before / after stage k's
     // gastric-emptying evaluation: the caller issues the LDS reads of a propagator row in pre() and consumes them
     // in post(), so that their latency hides behind ~50 dependent VALU instructions instead of being waited out.
-    // per-lane gut step and x2 weights (ADAPT: halved in flagged minutes; the flag is known after the first stage
-    // of the minute, whose value F1 = kgut x1 at the start does not depend on the step)
-    bool refine = FORCE;
-    auto gut_step = [&](auto&& pre, auto&& post, bool first_of_minute) {
+    auto gut_step = [&](auto&& pre, auto&& post, bool have_f1) {
         p.refresh();
         const T kmax = p(DP_KMAX);
         pre(0);
         T F1;
-        if (HAVE_F1 && first_of_minute) F1 = f1_pre; else F1 = kgutF(g0, g1);
+        if (HAVE_F1 && have_f1) F1 = f1_pre; else F1 = kgutF(g0, g1);
         post(0, F1);
-        if (ADAPT && !FORCE && first_of_minute) refine = gut_refine_flag(u, g0, g1, F1);
-        const T sc = (ADAPT && refine) ? T(0.5) : T(1);                 // exact scalings: the step sizes are not kept in registers
-        const T gh = sc * h, ghh = sc * hh, gh6 = sc * h6;
         const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;
         T y0 = g0 + ghh * a0, y1 = g1 + ghh * a1;
         pre(1);
@@ -525,41 +550,22 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
         const T F23 = F2 + F3;
         g0 += gh6 * (a0 + T(2) * (b0 + c0) + e0);
         g1 += gh6 * (a1 + T(2) * (b1 + c1) + e1);
-        const T wE = (ADAPT && refine) ? p(DP_X2E2) : p(DP_X2E), wA = (ADAPT && refine) ? p(DP_X2WA2) : p(DP_X2WA);
-        const T wM = (ADAPT && refine) ? p(DP_X2WM2) : p(DP_X2WM), wB = (ADAPT && refine) ? p(DP_X2WB2) : p(DP_X2WB);
-        const T x2n = wE * x2 + wA * F1 + wM * (T(0.5) * F23) + wB * F4;
+        const T x2n = p(W) * x2 + p(W + 1) * F1 + p(W + 2) * (T(0.5) * F23) + p(W + 3) * F4;
         R += (x2 - x2n) + gh6 * (F1 + T(2) * F23 + F4);     // d(x2 + R) = kgut x1 dt
         x2 = x2n;
     };
     auto no_pre = [](int) {};
     auto no_post = [](int, T) {};
-    auto glucose = [&](T y3, T y4, T y12, T cR, T cD, T X, T XL, T& d3, T& d4, T& d12) {
-        p.refresh();
-        const T x3 = y3 + cR;
-        const T egp = p(DP_KP1) - p(DP_KP2) * x3 - p(DP_KP3) * XL;                             // :153
-        const T et = p(DP_KE1) * t_max(x3 - p(DP_KE2), T(0));                                  // :158-161
-        const T k1x3 = p(DP_K1) * x3, k2x4 = p(DP_K2) * y4;
-        const T f3 = t_max(egp, T(0)) - p(DP_FSNC) - et - k1x3 + k2x4;                         // :165 without Rat
-        d3 = (x3 >= T(0)) ? f3 : -cD;                                                          // :167
-        const T vmt = p(DP_VM0) + p(DP_VMX) * X;                                               // :169
-        const T uid = fdiv_loop(vmt * y4, p(DP_KM0) + y4);                                     // :171
-        const T f4 = -uid + k1x3 - k2x4;                                                       // :172
-        d4 = (y4 >= T(0)) ? f4 : T(0);                                                         // :173
-        const T ksc = p(DP_KSC);
-        const T f12 = -ksc * y12 + ksc * x3;                                                   // :201
-        d12 = (y12 >= T(0)) ? f12 : T(0);                                                      // :202
-    };
 
     for (int s = 0; s < ns; ++s) {
-        // the propagator rows of this glucose step do not depend on the gut: evaluating them first lets their LDS
-        // reads and FMA chains fill the issue gaps of the gut steps' dependent chains (one row at a time: 28
-        // table reads in flight at once would cost 56 VGPRs)
-        // the four propagator rows of this glucose step ride along the four stages of the first gut step
-        const int r = s * 28;
+        // the four propagator rows of this glucose step (x6, x8 at its middle and at its end) ride along the four
+        // stages of its first gut step: one row at a time (28 table reads in flight at once would cost 56 VGPRs)
+        const int rm = ((2 * s + 1) * SB - 1) * 14, re = rm + SB * 14;
         T cf[7], x6m, x8m, x6b, x8b;
         auto pre = [&](int k) {
+            const int r = (k < 2 ? rm : re) + 7 * (k & 1);
 #pragma unroll
-            for (int j = 0; j < 7; ++j) cf[j] = pr(r + 7 * k + j);
+            for (int j = 0; j < 7; ++j) cf[j] = pr(r + j);
             __builtin_amdgcn_sched_barrier(0);           // the reads are issued here, ahead of the stage
         };
         auto post = [&](int k, T F) {
@@ -570,25 +576,30 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
             if (k == 0) x6m = v6; else if (k == 1) x8m = v8; else if (k == 2) x6b = v6; else x8b = v8;
         };
         gut_step(pre, post, s == 0);
-        if (ADAPT && refine) gut_step(no_pre, no_post, false);          // flagged lanes: the second half of this step
+        if (GM == 2) gut_step(no_pre, no_post, false);
         const T cRm = p(DP_CF) * R, cDm = p(DP_RATC) * x2;
         gut_step(no_pre, no_post, false);
-        if (ADAPT && refine) gut_step(no_pre, no_post, false);
+        if (GM == 2) gut_step(no_pre, no_post, false);
         const T cRb = p(DP_CF) * R, cDb = p(DP_RATC) * x2;
+        const bool hold = LEVEL != 0 && x3a < T(0);          // (level 0 is never chosen with x3 < 0)
+        T z3 = x3a - cRa;
         T k3, k4, k12, a3, a4, a12;
-        glucose(z3, x4, x12, cRa, cDa, x6a, x8a, k3, k4, k12);
+        if (HAVE_K1 && s == 0) { k3 = k3_pre; k4 = k4_pre; k12 = k12_pre; }
+        else glucose_rhs(p, z3, x4, x12, cRa, cDa, x6a, x8a, hold, x3a, k3, k4, k12);
         a3 = k3; a4 = k4; a12 = k12;
-        glucose(z3 + h * k3, x4 + h * k4, x12 + h * k12, cRm, cDm, x6m, x8m, k3, k4, k12);
+        glucose_rhs(p, z3 + h * k3, x4 + h * k4, x12 + h * k12, cRm, cDm, x6m, x8m, hold, x3a, k3, k4, k12);
         a3 += T(2) * k3; a4 += T(2) * k4; a12 += T(2) * k12;
-        glucose(z3 + h * k3, x4 + h * k4, x12 + h * k12, cRm, cDm, x6m, x8m, k3, k4, k12);
+        glucose_rhs(p, z3 + h * k3, x4 + h * k4, x12 + h * k12, cRm, cDm, x6m, x8m, hold, x3a, k3, k4, k12);
         a3 += T(2) * k3; a4 += T(2) * k4; a12 += T(2) * k12;
-        glucose(z3 + H * k3, x4 + H * k4, x12 + H * k12, cRb, cDb, x6b, x8b, k3, k4, k12);
+        glucose_rhs(p, z3 + H * k3, x4 + H * k4, x12 + H * k12, cRb, cDb, x6b, x8b, hold, x3a, k3, k4, k12);
         z3 += H6 * (a3 + k3); x4 += H6 * (a4 + k4); x12 += H6 * (a12 + k12);
+        const T x3b = z3 + cRb;
+        x3a = hold ? x3a : (x3b < T(0) ? T(-1e-10) : x3b);
         cRa = cRb; cDa = cDb; x6a = x6b; x8a = x8b;
     }
-    const int t0 = 14 * ng;
+    const int t0 = 28 * n_sub;
     x[0] = g0; x[1] = g1; x[2] = x2;
-    x[3] = z3 + cRa; x[4] = x4; x[12] = x12;
+    x[3] = x3a; x[4] = x4; x[12] = x12;
     x[6] = x6a; x[8] = x8a;
     x[5] = pr(t0) * s5 + pr(t0 + 1) * s9 + pr(t0 + 2) * s10 + pr(t0 + 3) * s11 + pr(t0 + 4) * ui;
     x[9] = pr(t0 + 5) * s5 + pr(t0 + 6) * s9 + pr(t0 + 7) * s10 + pr(t0 + 8) * s11 + pr(t0 + 9) * ui;
@@ -597,22 +608,40 @@ __device__ __forceinline__ void split_minute(P& p, const PR& pr, const MinuteIn<
     x[7] = pr(t0 + 15) * s7 + pr(t0 + 16) * s5 + pr(t0 + 17) * s9 + pr(t0 + 18) * s10 + pr(t0 + 19) * s11 + pr(t0 + 20) * ui;
 }
 
+// what the step-size rule needs at the start of the minute; F1 and the first glucose stage are reused by the integration
+template <typename T> struct TierPre { T f1, k3, k4, k12; int level; };
+template <typename T, typename P>
+__device__ __forceinline__ TierPre<T> tier_pre(P& p, const MinuteIn<T>& u, const T (&x)[13], int n_sub)
+{
+    TierPre<T> t;
+    t.f1 = kgut_flux(p, u, x[0], x[1]);
+    const T cD = p(DP_RATC) * x[2];
+    T q4;
+    glucose_rhs(p, x[3], x[4], x[12], T(0), cD, x[6], x[8], x[3] < T(0), x[3], t.k3, t.k4, t.k12, &q4);
+    t.level = tier_level(p, u, x, t.f1, t.k3 + cD, q4);          // dx3 = dz3 + c R' (0 while x3 < 0)
+    if (t.level == 0 && (n_sub & 3)) t.level = 1;                 // level 0 halves n_sub twice
+    return t;
+}
+
+// One minute, step sizes by the rule, every lane taking its own level in place (generic kernels; the single-minute
+// kernel sets lanes of levels 1 and 2 aside instead and integrates them together at the end of the launch).
+template <typename T, typename P, typename PR>
+__device__ __forceinline__ void split_minute_tiered(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub)
+{
+    const TierPre<T> t = tier_pre(p, u, x, n_sub);
+    if (t.level == 0) split_level<0, T, P, PR, true>(p, pr, u, x, n_sub, t.f1);
+    else if (t.level == 1) split_level<1, T, P, PR, true>(p, pr, u, x, n_sub, t.f1);
+    else split_level<2, T, P, PR, true>(p, pr, u, x, n_sub, t.f1);
+}
+
 template <int MATH, typename T, typename P>
 __device__ __forceinline__ void rk4_substeps(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub);
 
 // One minute of classical RK4 in n_sub sub-steps; replaces scipy's DOPRI5 (t1dpatient.py:110-113).
-// LOCAL: the RHS parameters are copied from the LDS table into VGPRs for the duration of the sub-step
-// loop only (28 ds_reads and one wait per minute): no LDS latency inside the loop, and no register is
-// held by a parameter outside it.
 template <int MATH, typename T, typename P>
-__device__ __forceinline__ void rk4_minute(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub, bool local_copy = false)
+__device__ __forceinline__ void rk4_minute(P& p, const MinuteIn<T>& u, T (&x)[13], int n_sub)
 {
-    if (MATH == 1 && local_copy) {
-        ParsReg<T> q;
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(kRhsPars) / sizeof(int)); ++k) q.v[kRhsPars[k]] = p(kRhsPars[k]);
-        rk4_substeps<MATH>(q, u, x, n_sub);
-    } else if (MATH == 1 && P::kSplitRk4) {
+    if (MATH == 1 && P::kSplitRk4) {
         rk4_substeps_split(p, u, x, n_sub);
     } else {
         rk4_substeps<MATH>(p, u, x, n_sub);

@@ -1,16 +1,15 @@
 // t1d_kernels.hpp -- the HIP kernels of libt1d_hip.so (gfx950 only).  Included by t1d_abi.hip, which holds the host
 // side of the C ABI (include/t1d.h); the per-lane arithmetic (RHS, integrators, sensor, risk) is in t1d_device.hpp.
 //
-//   step1_kernel       the headline launch: ONE simulated minute per env.step, split integrator, one persistent
-//                      workgroup per CU whose waves draw 64-env chunks from a queue in LDS.
-//   step1d_kernel      step1_kernel for the adaptive scheme: flagged envs are set aside in an LDS list and integrated
-//                      together, all lanes refining, once the CU's chunk queue is empty (the default for one-minute launches).
+//   step1d_kernel      the headline launch: ONE simulated minute per env.step, split integrator with per-minute step
+//                      sizes.  One persistent workgroup per CU whose waves draw 64-env chunks from a queue in LDS; the
+//                      main pass integrates the calm lanes (level 0, ~95 %) and sets the others aside in two lists in
+//                      LDS, which the waves work off -- 64 at a time, every lane at the list's level -- once the queue is empty.
+//   step1_kernel       the same launch with every lane integrated in place: the fixed-step form (level 1 everywhere),
+//                      tables of more than 32 patients, batches whose lists would not fit in LDS.
 //   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
-//                      n_sub sub-steps -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
-//   stepa_kernel, stepr_kernel  step_kernel for the adaptive scheme in two launches (large multi-minute batches): fixed
-//                      steps with flagged envs set aside, then those redone with the in-place rule.
+//                      integration -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
 //   refill_kernel      rebuilds due 150-minute CGM noise blocks ahead of a step kernel compiled without that code.
-//   step_pipe_kernel   step_kernel made persistent with LDS-DMA prefetch (classical RK4; experiment, off by default).
 //   rollout_pid_kernel n_steps x (PID or basal-bolus policy + step) with state in registers.
 //   reset_kernel       masked T1DSimEnv.reset().                                              (env.py:119-155)
 //   random_meals_kernel  RandomScenario.create_scenario for the whole batch.          (scenario_gen.py:33-60)
@@ -25,6 +24,15 @@
 #endif
 #ifndef T1D_ROW_RECOMPUTE
 #define T1D_ROW_RECOMPUTE 1
+#endif
+// Tuning builds only (-DT1D_AB_FLAGS=1): bits 0x100 / 0x200 / 0x400 / 0x800 of t1d_batch.flags switch the risk index,
+// the pump, the CGM noise and the integration off, to time the rest.  The shipped library is built without them and
+// t1d_step rejects unknown flag bits.
+#ifndef T1D_AB_FLAGS
+#define T1D_AB_FLAGS 0
+#endif
+#ifndef T1D_EXP
+#define T1D_EXP 0          // tuning builds: 4 = main pass keeps the first glucose stage of the step-size rule, 8 = main pass with LDS parameters
 #endif
 
 #include <climits>
@@ -46,9 +54,8 @@ template <typename T> struct KArgs {
     const T* minv;          // [11][11] knot second derivatives of the noise spline: M = minv . y
     int* status;
     long long* trace;       // T1D_S1_TRACE builds only: phase timestamps of the first blocks' waves
-    int* dseg; int* dcnt;   // stepa_kernel -> stepr_kernel: env indices set aside per 256-env tile [tiles][256], and how many [tiles]
     SensorC<T> sen; PumpC<T> pump;
-    int np, S, n_meals, n_normals, minutes, n_sub, flags, stagger, prop_rows, np_pad;
+    int np, S, n_meals, n_normals, minutes, n_sub, flags, prop_rows, np_pad;
 };
 
 template <typename T> struct PidArgs {
@@ -82,6 +89,7 @@ template <typename U> __device__ __forceinline__ U* row(U* base, int64_t n, int 
 }
 // row whose index may differ between lanes (meal cursor, noise block): ordinary per-lane address
 template <typename U> __device__ __forceinline__ U* rowv(U* base, int64_t n, int k) { return base + (int64_t)k * n; }
+template <typename A> __device__ __forceinline__ bool ab_flag(const A& a, int bit) { return T1D_AB_FLAGS && (a.flags & bit) != 0; }
 // element i of a uniform-base array through an explicit 32-bit BYTE offset (i < 2^28 by contract)
 // The access goes through an explicit address_space(1) pointer: row() hides a pointer's provenance, and a
 // pointer the compiler cannot trace back to a kernel argument is accessed with FLAT instructions, which
@@ -167,6 +175,7 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
 // rows it reads do not depend on the env's clock (they can be fetched with the rest of the state).
 // pts rows: 0..10 = y (points of the block), 11..21 = M, 22..25 = (y_m, y_{m+1}, M_m, M_{m+1}).
 constexpr int kPtsRows = 26;
+constexpr int kPackedRows = 18 + kPtsRows;            // rows of the packed state buffer (include/t1d.h): 44
 
 #ifndef T1D_REFILL_INLINE
 #define T1D_REFILL_INLINE 1
@@ -320,21 +329,14 @@ __device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& 
 }
 
 // T1DSimEnv.step body (env.py:66-84): `minutes` mini_steps with one action.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-
-// `pre_rk4` runs once, immediately before the first minute's RK4 sub-steps: from there to the end of
-// the integration the wave issues no vector-memory instruction, which is where the persistent kernel
-// starts the LDS-DMA of its next tile.
-// ABORT (fixed-step split integrator, stepa_kernel): a lane that meets a minute asking for the adaptive scheme's
-// refinement stops there and reports it through *aborted; the caller stores nothing of it.
-template <int MATH, typename T, typename P, typename Hook = NoHook, bool LOCALP = false, bool REFILL = true, typename PR = NoProp,
-          bool ABORT = false>
+// PR = NoProp: classical RK4 on all 13 states; otherwise the split integrator, TIERED: step sizes by the rule of
+// t1d_device.hpp (every lane its own level, in place), else level 1 in every minute.
+template <int MATH, typename T, typename P, bool REFILL = true, typename PR = NoProp, bool TIERED = false>
 __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigned i, Env<T>& e,
-                                                T basal, T bolus, bool has_bolus, Hook pre_rk4 = Hook(), PR pr = PR(),
-                                                bool* aborted = nullptr)
+                                                T basal, T bolus, bool has_bolus, PR pr = PR())
 {
     T q_basal, q_bolus;
-    if (a.flags & (T1D_BATCH_NO_PUMP | 0x200)) { // T1DPatient.step driven directly: insulin = basal + bolus as given
+    if ((a.flags & T1D_BATCH_NO_PUMP) || ab_flag(a, 0x200)) { // T1DPatient.step driven directly: insulin = basal + bolus as given
         q_basal = basal; q_bolus = has_bolus ? bolus : T(0);
     } else {
         q_basal = pump_quantise(basal, a.pump.inc_basal, a.pump.min_basal, a.pump.max_basal);   // env.py:51
@@ -347,27 +349,14 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
     for (int m = 0; m < a.minutes; ++m) {
         const T meal = a.cho ? at(row(a.cho, a.n, m), i) : meal_lookup(a, i, e);      // env.py:50
         bool due;
-        const T noise = (a.flags & 0x400) ? (due = false, T(0)) : measure_noise<REFILL>(a, i, e, due);
+        const T noise = ab_flag(a, 0x400) ? (due = false, T(0)) : measure_noise<REFILL>(a, i, e, due);
         MinuteIn<T> u = eat_minute<MATH, T>(p, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
-        // every load this minute issued is needed by the integration anyway: drain them HERE, on every
-        // path, so that the compiler's own wait cannot land behind the hook's (invisible) DMA instructions
         if constexpr (PR::kSplit) p.pin_split(); else p.pin();
-        {   // volatile asms keep their order: everything the RK4 loop consumes is computed (and any spilled
-            // operand reloaded) BEFORE the hook below issues its DMA
-            T aa = u.aa, cc = u.cc, bD = u.bD, dD = u.dD, dmg = u.d_mg, ins = u.ins;
-            asm volatile("" : "+v"(aa), "+v"(cc), "+v"(bD), "+v"(dD), "+v"(dmg), "+v"(ins));
-            u.aa = aa; u.cc = cc; u.bD = bD; u.dD = dD; u.d_mg = dmg; u.ins = ins;
+        if (!ab_flag(a, 0x800)) {
+            if constexpr (PR::kSplit && TIERED) split_minute_tiered(p, pr, u, e.x, a.n_sub);
+            else if constexpr (PR::kSplit) split_level<1>(p, pr, u, e.x, a.n_sub);
+            else rk4_minute<MATH>(p, u, e.x, a.n_sub);
         }
-        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
-        if (m == 0) pre_rk4();
-        if constexpr (ABORT) {
-            static_assert(PR::kSplit && !PR::kAdapt && !REFILL, "abort-on-flag goes with the fixed-step split integrator");
-            const T f1 = kgut_flux(p, u, e.x[0], e.x[1]);
-            if (gut_refine_flag(u, e.x[0], e.x[1], f1)) { *aborted = true; break; }
-            if (!(a.flags & 0x800)) split_minute<T, P, PR, true>(p, pr, u, e.x, a.n_sub, f1);
-        } else
-        if constexpr (PR::kSplit) { if (!(a.flags & 0x800)) split_minute(p, pr, u, e.x, a.n_sub); }
-        else { if (!(a.flags & 0x800)) rk4_minute<MATH>(p, u, e.x, a.n_sub, LOCALP); }
         e.t += 1;
         const T gsub = MATH == 0 ? e.x[12] / p(DP_VG) : e.x[12] * p(DP_IVG);      // t1dpatient.py:217-218
         const T cgm = measure_apply(a, e, gsub, noise, due);                      // env.py:62
@@ -384,7 +373,7 @@ template <int MATH, typename T>
 __device__ __forceinline__ T prev_risk(const KArgs<T>& a, T prev_cgm)
 {
     T l, h, rp = T(0);
-    if (!(a.flags & 0x100)) risk_index1<MATH>(prev_cgm, l, h, rp);
+    if (!ab_flag(a, 0x100)) risk_index1<MATH>(prev_cgm, l, h, rp);
     return rp;
 }
 
@@ -392,7 +381,7 @@ template <int MATH, typename T>
 __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env<T>& e, const StepOut<T>& o, T rp)
 {
     T l, h, r, rc = T(0);
-    if (!(a.flags & 0x100)) risk_index1<MATH>(o.cgm, l, h, rc);
+    if (!ab_flag(a, 0x100)) risk_index1<MATH>(o.cgm, l, h, rc);
     at(a.reward, i) = rp - rc;
     e.prev_cgm = o.cgm;
     at(a.cgm, i) = o.cgm; at(a.bg, i) = o.bg;
@@ -408,19 +397,16 @@ __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env
     if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
 }
 
-// VARIANT 0: reference arithmetic (ocml tanh, IEEE divisions), parameters from LDS
-//         1: fast arithmetic, parameters re-read from LDS per RHS evaluation (any patient layout)
-//         2: fast arithmetic, wave-uniform patient, parameters in SGPRs (T1D_BATCH_WAVE_UNIFORM)
-//         3: fast arithmetic, parameters gathered once per lane into VGPRs (any patient layout)
-//         4: as 3, split integrator (t1d_device.hpp) with the insulin propagator staged in LDS
-//         5: as 1, split integrator
-//         6, 7: as 4, 5 with the adaptive gut refinement
+// VARIANT 0: reference arithmetic (ocml tanh, IEEE divisions as t1dpatient.py writes them), classical RK4, parameters from LDS
+//         3: fast arithmetic, classical RK4 evaluated sub-system by sub-system, parameters gathered once per lane into VGPRs
+//         4: fast arithmetic, split integrator at level 1 in every minute, VGPR parameters
+//         7: fast arithmetic, split integrator with per-minute step sizes taken in place, parameters from LDS
 template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
 template <int VARIANT> struct VariantInfo {
-    static constexpr bool split = VARIANT >= 4 && VARIANT <= 7;
-    static constexpr bool adapt = VARIANT == 6 || VARIANT == 7;
-    static constexpr bool lds_pars = VARIANT == 0 || VARIANT == 1 || VARIANT == 5 || VARIANT == 7;
-    static constexpr bool reg_pars = VARIANT == 3 || VARIANT == 4 || VARIANT == 6;
+    static_assert(VARIANT == 0 || VARIANT == 3 || VARIANT == 4 || VARIANT == 7, "unknown kernel variant");
+    static constexpr bool split = VARIANT == 4 || VARIANT == 7;
+    static constexpr bool tiered = VARIANT == 7;
+    static constexpr bool lds_pars = VARIANT == 0 || VARIANT == 7;
 };
 extern __shared__ __align__(16) unsigned char t1d_dyn_lds[];
 
@@ -444,124 +430,35 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
     const T rp = prev_risk<MATH>(a, e.prev_cgm);
     StepOut<T> o;
-    if constexpr (VARIANT == 4 || VARIANT == 6) {
+    if constexpr (VARIANT == 4) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
-        PropLds<T, VI::adapt> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
-        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL, PropLds<T, VI::adapt>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
-    } else if constexpr (VARIANT == 5 || VARIANT == 7) {
+        o = step_body<MATH, T, ParsReg<T>, REFILL, PropLds<T>, false>(a, p, i, e, basal, bolus, a.bolus != nullptr, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+    } else if constexpr (VARIANT == 7) {
         ParsLds<T> p{lds, (int)pid};
-        PropLds<T, VI::adapt> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
-        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL, PropLds<T, VI::adapt>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
-    } else if constexpr (VARIANT == 2) {
-        const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
-        if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
-        ParsScalar<T> p;
-        p.load(a.dpar, kMaxPatients, pid0);
-        o = step_body<MATH, T, ParsScalar<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+        o = step_body<MATH, T, ParsLds<T>, REFILL, PropLds<T>, true>(a, p, i, e, basal, bolus, a.bolus != nullptr, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
     } else if constexpr (VARIANT == 3) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
-        o = step_body<MATH, T, ParsReg<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+        o = step_body<MATH, T, ParsReg<T>, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
     } else {
         ParsLds<T> p{lds, (int)pid};
-        o = step_body<MATH, T, ParsLds<T>, NoHook, false, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
+        o = step_body<MATH, T, ParsLds<T>, REFILL>(a, p, i, e, basal, bolus, a.bolus != nullptr);
     }
     write_outputs<MATH>(a, i, e, o, rp);
     store_env(a, i, pid, e);
 }
 
-// ---- any minutes per launch, split integrator, adaptive refinement in a launch of its own ----------------
-// step_kernel<6/7> refines in place: a wave with one flagged lane runs the extra half steps of that minute for the
-// one lane; over a 3-minute step ~3 % of the lanes are flagged at some point, so most waves pay, and the adaptive rule
-// keeps the parameters out of the VGPRs (+45 % over fixed steps at 1 Mi envs).  stepa_kernel is step_kernel<4> (fixed
-// steps, VGPR parameters) except that a lane meeting a flagged minute stops -- nothing of it has been stored: the
-// generic kernel stores at the end of the step -- and leaves its env index in its tile's segment of a scratch
-// buffer; stepr_kernel then redoes those envs with the in-place rule, each wave gathering the segments of
-// kDeferGroup tiles (~30 envs of 1 024).  Worth a second launch from ~3/4 Mi envs up (t1d_step decides).
-constexpr int kDeferGroup = 4;
-
-template <typename T>
-__global__ __launch_bounds__(kBlock, T1D_WAVES) void stepa_kernel(const KArgs<T> a)
-{
-    __shared__ int nab;
-    if (threadIdx.x == 0) nab = 0;
-    stage_prop(a, (T*)t1d_dyn_lds);                      // ends in a barrier
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    __builtin_assume(i < (1u << 28));
-    if ((int64_t)i < a.n) {
-        const uint32_t meta = at(a.meta, i);
-        const uint32_t pid = T1D_META_PID(meta);
-        Env<T> e;
-        load_env(a, i, meta, e);
-        const T basal = at(a.basal, i);
-        const T bolus = a.bolus ? at(a.bolus, i) : T(0);
-        const T rp = prev_risk<1>(a, e.prev_cgm);
-        ParsReg<T> p;
-        p.load(a.dpar, (int)pid);
-        PropLds<T, false> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
-        bool aborted = false;
-        StepOut<T> o = step_body<1, T, ParsReg<T>, NoHook, false, false, PropLds<T, false>, true>(
-            a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr, &aborted);
-        if (aborted) {
-            a.dseg[blockIdx.x * kBlock + atomicAdd(&nab, 1)] = (int)i;
-        } else {
-            write_outputs<1>(a, i, e, o, rp);
-            store_env(a, i, pid, e);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) a.dcnt[blockIdx.x] = nab;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock, T1D_WAVES) void stepr_kernel(const KArgs<T> a, int ntiles)
-{
-    __shared__ T lds[DP_COUNT * kMaxPatients];
-    stage_pars(a, lds, DP_COUNT);
-    stage_prop(a, (T*)t1d_dyn_lds);
-    const int lane = threadIdx.x & 63;
-    const int tile0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kDeferGroup;     // wave-uniform
-    int cnt[kDeferGroup], total = 0;
-#pragma unroll
-    for (int k = 0; k < kDeferGroup; ++k) {
-        cnt[k] = tile0 + k < ntiles ? a.dcnt[tile0 + k] : 0;
-        total += cnt[k];
-    }
-    for (int base = 0; base < total; base += 64) {       // one round unless much more than usual was set aside
-        int idx = base + lane;
-        if (idx >= total) continue;
-        int tile = tile0;
-#pragma unroll
-        for (int k = 0; k < kDeferGroup - 1; ++k)
-            if (idx >= cnt[k] && tile == tile0 + k) { idx -= cnt[k]; ++tile; }
-        const unsigned i = (unsigned)a.dseg[tile * kBlock + idx];
-        __builtin_assume(i < (1u << 28));
-        const uint32_t meta = at(a.meta, i);
-        const uint32_t pid = T1D_META_PID(meta);
-        Env<T> e;
-        load_env(a, i, meta, e);
-        const T basal = at(a.basal, i);
-        const T bolus = a.bolus ? at(a.bolus, i) : T(0);
-        const T rp = prev_risk<1>(a, e.prev_cgm);
-        ParsLds<T> p{lds, (int)pid};
-        PropLds<T, true> pr{(const T*)t1d_dyn_lds, a.np_pad, (int)pid};
-        StepOut<T> o = step_body<1, T, ParsLds<T>, NoHook, false, false, PropLds<T, true>>(a, p, i, e, basal, bolus, a.bolus != nullptr, NoHook(), pr);
-        write_outputs<1>(a, i, e, o, rp);
-        store_env(a, i, pid, e);
-    }
-}
-
 // ---- single-minute step, split integrator, persistent blocks -----------------------------------------
 // The launch the headline workload makes a million times: one simulated minute per env.step (1-min sensors),
 // no noise-block refill due (refill_kernel ran, or the host vouched).  Differences from step_kernel:
-//   * blocks are persistent (grid = what is resident) and walk tiles of 256 envs, so the parameter and
+//   * blocks are persistent (grid = what is resident) and walk chunks of 64 envs, so the parameter and
 //     propagator tables are staged into LDS once per block instead of once per 256 envs, compactly
 //     (row stride 32 or 64 patients, a compile-time constant: every table read is a ds_read with an
 //     immediate offset);
 //   * everything the integration does not need is stored BEFORE it (meal bookkeeping, clock, meal cursor,
 //     insulin/meal outputs), so that only the 13 states, the drawn noise and the previous risk are alive
-//     across the sub-step loops -- which is what lets four waves share a SIMD (<= 128 VGPRs) where
+//     across the sub-step loops -- which is what lets three waves share a SIMD (<= 168 VGPRs) where
 //     step_kernel needs ~230.
 #ifndef T1D_S1_WAVES
 #define T1D_S1_WAVES 3
@@ -574,7 +471,7 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void stepr_kernel(const KArgs<T>
 #endif
 #if T1D_S1_TRACE
 // tuning builds: drain every counter and stamp the wall clock (100 MHz) at phase boundaries
-#define S1_MARK(m) do { __builtin_amdgcn_s_waitcnt(0x0070); if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + (m)] = (long long)wall_clock64(); } while (0)
+#define S1_MARK(m) do { __builtin_amdgcn_s_waitcnt(0x0070); if (tr && (threadIdx.x & 63) == 0 && tk < 6) tr[tk * 8 + (m)] = (long long)wall_clock64(); } while (0)
 #else
 #define S1_MARK(m) do { } while (0)
 #endif
@@ -583,16 +480,17 @@ constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a C
 // third risk evaluation drop out of the kernel altogether
 //
 // One env-minute of one lane: everything between the chunk's loads and its last store.  MODE:
-//   0  fixed gut steps;
-//   1  adaptive, in place: flagged lanes take their halved gut steps under their exec mask (split_minute);
-//   2  main pass of step1d_kernel: fixed steps; the refinement flag is evaluated right after the meal bookkeeping
-//      and handed to on_flag(flag) -- a flagged lane stops there, before anything is stored;
-//   3  deferred pass of step1d_kernel: every lane was flagged, every lane takes the halved steps.
-template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONFLAG>
-__device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, ONFLAG&& on_flag,
+//   0  level 1 for every lane (the fixed-step form of the scheme);
+//   1  step sizes by the rule, every lane its own level in place (split_minute_tiered);
+//   2  main pass of step1d_kernel: the level is evaluated right after the meal bookkeeping and handed to
+//      on_level(level); lanes of level 0 integrate, the others stop there -- before anything is stored;
+//   3  deferred pass of step1d_kernel over the lanes of level 1;
+//   4  ... of level 2.
+template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONLEVEL>
+__device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, ONLEVEL&& on_level,
                                          long long* tr, int tk)
 {
-    constexpr bool ADAPT = MODE == 1 || MODE == 3;
+    constexpr int LEVEL = MODE == 2 ? 0 : (MODE == 4 ? 2 : 1);        // the level this pass integrates at (modes 0, 2, 3, 4)
     (void)tr; (void)tk;
     S1_MARK(0);
     const uint32_t meta = at(row(a.t, a.n, 1), i);
@@ -625,12 +523,11 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
     ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
     MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
-    T f1 = T(0);
+    TierPre<T> tp{T(0), T(0), T(0), T(0), LEVEL};
     if (MODE == 2) {
-        f1 = kgut_flux(pl, u, e.x[0], e.x[1]);
-        const bool flag = gut_refine_flag(u, e.x[0], e.x[1], f1);
-        on_flag(flag);
-        if (flag) return;                            // nothing stored: the deferred pass redoes this lane from its loads
+        tp = tier_pre(pl, u, e.x, a.n_sub);
+        on_level(tp.level);
+        if (tp.level != 0) return;                   // nothing stored: a deferred pass redoes this lane from its loads
     }
     // bookkeeping is final for this minute: store it now -- the meal words only where they changed (they do
     // while an env is eating, ~3 % of the minutes: 24 B per env-step of write traffic otherwise)
@@ -648,20 +545,20 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         if (a.insulin) at(a.insulin, i) = insulin;
     }
     S1_MARK(2);
-    {
-        PropLdsS<T, STRIDE, ADAPT, MODE == 3> pr{lpr, (int)pid};
-        if (REG) {
+    if (!ab_flag(a, 0x800)) {
+        PropLdsS<T, STRIDE> pr{lpr, (int)pid};
+        if (MODE == 1) {
+            split_minute_tiered(pl, pr, u, e.x, a.n_sub);
+        } else if (REG) {
             ParsReg<T> p;
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
-            if (ADAPT) {
 #pragma unroll
-                for (int k = 0; k < (int)(sizeof(kAdaptPars) / sizeof(int)); ++k) p.v[kAdaptPars[k]] = pl(kAdaptPars[k]);
-            }
+            for (int k = 0; k < 4; ++k) p.v[kSplitW(LEVEL) + k] = pl(kSplitW(LEVEL) + k);
             p.pin_split();
-            if (!(a.flags & 0x800)) split_minute<T, ParsReg<T>, decltype(pr), MODE == 2>(p, pr, u, e.x, a.n_sub, f1);
+            split_level<LEVEL, T, ParsReg<T>, decltype(pr), MODE == 2, MODE == 2 && (T1D_EXP & 4) != 0>(p, pr, u, e.x, a.n_sub, tp.f1, tp.k3, tp.k4, tp.k12);
         } else {
-            if (!(a.flags & 0x800)) split_minute<T, ParsLdsS<T, STRIDE>, decltype(pr), MODE == 2>(pl, pr, u, e.x, a.n_sub, f1);
+            split_level<LEVEL, T, ParsLdsS<T, STRIDE>, decltype(pr), MODE == 2, MODE == 2 && (T1D_EXP & 4) != 0>(pl, pr, u, e.x, a.n_sub, tp.f1, tp.k3, tp.k4, tp.k12);
         }
     }
     S1_MARK(3);
@@ -689,7 +586,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         if (a.sen.st != 1) at(row(a.x, a.n, 16), i) = c;      // the zero-order hold is dead state with a 1-minute sensor
     }
     T l, h, r, rc = T(0);
-    if (!(a.flags & 0x100)) risk_index1<1>(last_cgm, l, h, rc);
+    if (!ab_flag(a, 0x100)) risk_index1<1>(last_cgm, l, h, rc);
     at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
     at(row(a.x, a.n, 17), i) = last_cgm;
     at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
@@ -702,14 +599,14 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     }
     if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
 #if T1D_S1_TRACE
-    if (tr && (threadIdx.x & 63) == 0 && tk < 8) tr[tk * 8 + 5] = (long long)wall_clock64();    // epilogue computed, stores issued
+    if (tr && (threadIdx.x & 63) == 0 && tk < 6) tr[tk * 8 + 5] = (long long)wall_clock64();    // epilogue computed, stores issued
 #endif
     S1_MARK(6);
 }
 
-struct S1NoFlag { __device__ __forceinline__ void operator()(bool) const {} };
+struct S1NoLevel { __device__ __forceinline__ void operator()(int) const {} };
 
-// tables of one CU, staged once per launch; returns nothing: ldp = [DP_COUNT][STRIDE], lpr = [prop_rows][STRIDE]
+// tables of one CU, staged once per launch: ldp = [DP_COUNT][STRIDE], lpr = [prop_rows][STRIDE]
 template <typename T, int STRIDE>
 __device__ __forceinline__ void s1_stage_tables(const KArgs<T>& a, T* ldp, T* lpr, T* lconst)
 {
@@ -740,7 +637,8 @@ __device__ __forceinline__ void s1_rotate_prio(int it)
 #endif
 }
 
-template <bool REG, typename T, int STRIDE, bool EXTRA, bool ADAPT>
+// every lane in place: TIERED = step sizes by the rule (LDS parameters), else level 1 everywhere (VGPR parameters)
+template <typename T, int STRIDE, bool EXTRA, bool TIERED>
 __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
@@ -777,36 +675,47 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         if ((int64_t)i >= a.n) continue;
         ++tk;
         s1_rotate_prio(it);
-        s1_chunk<REG, T, STRIDE, EXTRA, ADAPT ? 1 : 0>(a, ldp, lpr, lconst, i, S1NoFlag(), tr, tk);
+        s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, S1NoLevel(), tr, tk);
     }
 }
 
-// step1_kernel with the adaptive scheme's refinement DEFERRED.  In place (MODE 1 above) a wave with one flagged lane
-// runs the four extra half steps of the minute for that one lane: 0.7 % of the env-minutes of random-meal days are
-// flagged, but 37 % of the waves hold at least one, and the launch pays +17 %.  Here the main pass integrates with
-// fixed steps and a flagged lane only leaves its env index in a list in LDS (before anything of it is stored);
-// waves that find the chunk queue empty wait until every chunk of the CU is past that point and then take the
-// listed envs 64 at a time, all lanes refining.  The list holds every env of the CU's share (t1d_step sizes it),
-// so it cannot overflow; the per-lane arithmetic is that of MODE 1, lane for lane.
-// DREG: the deferred pass too takes its parameters from VGPRs.  A short launch is latency-bound and ends with that
-// pass, where LDS round trips in the dependent chains count (1 024 envs: 12.8 vs 14.8 us); it costs 3 spilled
-// registers, which a long launch is better off without (t1d_step picks by chunks per CU).
-template <bool REG, typename T, int STRIDE, bool EXTRA, bool DREG = false>
+// The single-minute launch with per-minute step sizes.  Taken in place (step1_kernel<.., true>) a wave runs at the
+// highest level among its lanes: ~4 % of the env-minutes of random-meal days are at level 1 and ~1.3 % at level 2,
+// so almost every wave would pay for level 1 and half of them for level 2 (3.5 x level 1).  Here the main pass
+// integrates the lanes of level 0 -- half the arithmetic of level 1 -- and a lane of another level only leaves its env
+// index in that level's list in LDS (before anything of it is stored); waves that find the chunk queue empty wait
+// until every chunk of the CU is past that point and then take the listed envs 64 at a time, first the long level 2,
+// then level 1, from their loads, every lane at the list's level.  The lists hold every env of the CU's share
+// (t1d_step sizes them), so they cannot overflow; per-lane arithmetic is that of the in-place form, lane for lane.
+// DREG: the deferred passes too take their parameters from VGPRs.  A short launch is latency-bound and ends with
+// those passes, where LDS round trips in the dependent chains count; a long launch is better off without the few
+// registers that spills (t1d_step picks by chunks per CU).
+template <typename T, bool EXTRA, bool DREG = false>
 __global__ __launch_bounds__(kS1Threads, 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
+    constexpr int STRIDE = 32;
     T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
-    int* const dlist = (int*)(lpr + a.prop_rows * STRIDE); // [per_block * 64] env indices awaiting refinement
-    __shared__ int queue, queue2, dcount, passed;
+    const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
+    int* const list1 = (int*)(lpr + a.prop_rows * STRIDE); // [per_block * 64] env indices of level 1
+    int* const list2 = list1 + per_block * 64;             // [per_block * 64] ... of level 2
+    __shared__ int queue, taken1, taken2, n1, n2, passed;
     __shared__ T lconst[8];
     s1_stage_tables<T, STRIDE>(a, ldp, lpr, lconst);
-    if (threadIdx.x == 0) { queue = 0; queue2 = 0; dcount = 0; passed = 0; }
+    if (threadIdx.x == 0) { queue = 0; taken1 = 0; taken2 = 0; n1 = 0; n2 = 0; passed = 0; }
     __syncthreads();
-    const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
     const int first = (int)blockIdx.x * per_block;
     const int count = nchunks - first < per_block ? nchunks - first : per_block;
     const unsigned lane = threadIdx.x & 63u;
     long long* tr = nullptr;
+#if T1D_S1_TRACE
+    // tuning builds: wall clock (100 MHz) of every wave of the first 32 workgroups at the phase boundaries of the launch
+    long long* const ph = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (kS1Threads / 64) + threadIdx.x / 64) * 64 : nullptr;
+#define S1D_PHASE(k) do { if (ph && lane == 0) ph[k] = (long long)wall_clock64(); } while (0)
+#else
+#define S1D_PHASE(k) do { } while (0)
+#endif
+    S1D_PHASE(0);
     int it = 0;
     for (;; ++it) {
         int c = 0;
@@ -817,194 +726,59 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1d_kernel(const KArgs<T> a,
         __builtin_assume(i < (1u << 28));
         s1_rotate_prio(it);
         if ((int64_t)i < a.n) {
-            s1_chunk<REG, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, [&](bool flag) {
-                if (flag) dlist[atomicAdd(&dcount, 1)] = (int)i;
-                // lane 0 of a chunk is always a live env: it reports the chunk past its flag point, after the
+#if T1D_S1_TRACE
+            tr = ph ? ph + 16 : nullptr;                    // per-chunk phase marks of the wave's first six chunks
+#endif
+            s1_chunk<!(T1D_EXP & 8), T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, [&](int level) {
+                if (level == 1) list1[atomicAdd(&n1, 1)] = (int)i;
+                else if (level == 2) list2[atomicAdd(&n2, 1)] = (int)i;
+                // lane 0 of a chunk is always a live env: it reports the chunk past its decision point, after the
                 // list entries of the wave (LDS operations of one wave execute in order)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) atomicAdd(&passed, 1);
-            }, tr, 0);
+            }, tr, it);
         }
     }
-    // every chunk of this CU has been drawn; those still in flight may yet add to the list
+    tr = nullptr;
+    S1D_PHASE(1);
+    // every chunk of this CU has been drawn; those still in flight may yet add to the lists
     while (__hip_atomic_load(&passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < count) __builtin_amdgcn_s_sleep(4);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const int total = __hip_atomic_load(&dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    for (;; ++it) {
-        int g = 0;
-        if (lane == 0) g = atomicAdd(&queue2, 1);
-        g = __builtin_amdgcn_readfirstlane(g);
-        if (g * 64 >= total) break;                         // wave-uniform
-        const int idx = g * 64 + (int)lane;
-        __builtin_amdgcn_s_setprio(3);                      // the launch ends with this pass: it goes first on its SIMD
-        if (idx < total) {
-            const unsigned i = (unsigned)dlist[idx];
-            __builtin_assume(i < (1u << 28));
-            s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoFlag(), tr, 0);
-        }
-    }
-}
-
-// ---- persistent, software-pipelined step ---------------------------------------------------------
-// One-tile-per-block launches keep the two waves of a SIMD in lock-step: both wait for their loads,
-// then both compete for the VALU, then both store, so the chip alternates between an idle VALU and an
-// idle memory system (measured: ~60-90 us of a 150-170 us launch at 1 Mi envs).  Here each block walks
-// tiles blockIdx.x, +gridDim.x, ... and every wave streams the state of its NEXT 64 envs from HBM
-// straight into a wave-private LDS staging area with LDS-DMA (global_load_lds_dwordx4: no VGPR is
-// held by data in flight) while it integrates the current 64.  Nothing but the issuing wave's vmcnt
-// orders a ds_read behind a pending LDS-DMA, hence the explicit waits.
-typedef __attribute__((address_space(1))) const void t1d_gptr;
-typedef __attribute__((address_space(3))) void t1d_lptr;
-
-// The pipelined kernel needs the per-env state PACKED: one [44][n] buffer of T (rows 0-12 x, 13 planned,
-// 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_cgm, 18-43 pts) and one [3+][n] int buffer (t, meta,
-// next_meal), so that every staged row is `base + 32-bit offset` (t1d_step checks the pointers and
-// falls back to step_kernel otherwise).  Stage rows: 0-17 = state rows 0-17, 18-21 = pts rows 22-25
-// (state rows 40-43), 22.. = basal, 22+G.. = bolus (each DMA group fetches G rows: 2 for double, 4 for float).
-constexpr int kPackedRows = 18 + kPtsRows;            // 44
-template <typename T> struct StageGeom {
-    static constexpr int EPL = 16 / (int)sizeof(T);   // elements per lane per DMA
-    static constexpr int LPR = 64 / EPL;              // lanes per 64-element row
-    static constexpr int G = 64 / LPR;                // rows per DMA instruction (2 / 4)
-    static constexpr int BASAL = 24;                  // first stage row of the basal group
-    static constexpr int BOLUS = BASAL + G;
-    static constexpr int ROWS = BOLUS + G;
-};
-template <typename T> struct Stage {
-    T f[StageGeom<T>::ROWS][64];
-    int i[4][64];
-};
-
-// One LDS-DMA: lane l fetches 16 B at base + voff; the 1 KiB lands contiguously at lds_dst (M0).
-// Issued through inline asm on purpose: when hipcc knows about a pending LDS-DMA it puts an
-// `s_waitcnt vmcnt(0)` in front of EVERY later LDS read (here: the parameter table inside the RK4
-// loop), which serialises the prefetch with the arithmetic it is meant to hide under.  The loop in
-// step_pipe_kernel counts and waits for these operations itself.
-__device__ __forceinline__ void dma16(const void* base_uniform, unsigned voff, void* lds_dst)
-{
-    const unsigned lds_addr = (unsigned)(size_t)(t1d_lptr*)lds_dst;
-    unsigned saved_m0;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(saved_m0) : "v"(voff), "s"(base_uniform), "s"(lds_addr) : "memory");
-}
-
-template <typename T>
-__device__ __forceinline__ void stage_tile(const KArgs<T>& a, unsigned elem0, Stage<T>* st)
-{
-    using GEO = StageGeom<T>;
-    unsigned lane = threadIdx.x & 63u;
-    asm volatile("" : "+v"(lane));       // recompute the few offsets here: hoisted out of the tile loop they get spilled,
-                                         // and a scratch reload between two DMAs is a vmcnt(0) that waits for the first
-    const unsigned rowb = (unsigned)a.n * (unsigned)sizeof(T);                       // bytes per state row
-    const unsigned v0 = elem0 * (unsigned)sizeof(T) + (lane / GEO::LPR) * rowb + (lane % GEO::LPR) * 16u;
-    const void* xb = a.x;
-#pragma unroll
-    for (int r = 0; r < 18; r += GEO::G) dma16(xb, v0 + (unsigned)r * rowb, &st->f[r][0]);   // rows 0..17 (+ spill-over into 18, 19 for float)
-#pragma unroll
-    for (int r = 0; r < 4; r += GEO::G) dma16(xb, v0 + (unsigned)(40 + r) * rowb, &st->f[20 + r][0]);
-    const unsigned vsame = elem0 * (unsigned)sizeof(T) + (lane % GEO::LPR) * 16u;  // every row group = the same row
-    dma16(a.basal, vsame, &st->f[GEO::BASAL][0]);
-    if (a.bolus) dma16(a.bolus, vsame, &st->f[GEO::BOLUS][0]);
-    const unsigned rowi = (unsigned)a.n * 4u;
-    const unsigned li = lane / 16u;
-    dma16(a.t, elem0 * 4u + (li < 3u ? li : 0u) * rowi + (lane % 16u) * 16u, &st->i[0][0]);
-}
-
-template <typename T>
-__device__ __forceinline__ void unstage(const KArgs<T>& a, const Stage<T>* st, Env<T>& e, T& basal, T& bolus, uint32_t& meta)
-{
-    using GEO = StageGeom<T>;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < 13; ++k) e.x[k] = st->f[k][lane];
-    e.planned = st->f[13][lane]; e.lq = st->f[14][lane]; e.lf = st->f[15][lane];
-    e.last_cgm = st->f[16][lane]; e.prev_cgm = st->f[17][lane];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e.cur[k] = st->f[20 + k][lane];
-    basal = st->f[GEO::BASAL][lane];
-    bolus = a.bolus ? st->f[GEO::BOLUS][lane] : T(0);
-    e.t = st->i[0][lane];
-    meta = (uint32_t)st->i[1][lane];
-    e.next_meal = st->i[2][lane];
-    e.next_meal_loaded = e.next_meal;
-    e.eating = (meta & T1D_META_EATING) != 0;
-    e.cursor = (int)T1D_META_CURSOR(meta);
-}
-
-// requires a.n % kBlock == 0 and the packed state layout (the host falls back to step_kernel otherwise)
-template <int VARIANT, typename T>
-__global__ __launch_bounds__(kBlock, T1D_WAVES) void step_pipe_kernel(const KArgs<T> a)
-{
-    constexpr int MATH = 1;
-    __shared__ T lds[VARIANT == 2 ? 1 : DP_RK4_COUNT * kMaxPatients];
-    __shared__ Stage<T> stage[kBlock / 64];
-    if (VARIANT != 2) stage_pars(a, lds, DP_RK4_COUNT);
-    const unsigned ntiles = (unsigned)(a.n / kBlock);
-    unsigned tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    Stage<T>* st = &stage[wave];
-    // Identical waves that start together stay in lock-step: both waves of a SIMD are in their latency-bound
-    // prologue/epilogue at the same time and in the VALU-dense RK4 loop at the same time.  Delaying the
-    // second half of the grid (the second workgroup of each CU under round-robin dispatch) by a fraction
-    // of a tile puts the pairs out of phase for the rest of the launch.
-    if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2)
-        for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-    stage_tile(a, tile * kBlock + (unsigned)wave * 64u, st);
-    bool first = true;
+    __builtin_amdgcn_s_setprio(3);                          // the launch ends with these passes: they go first on their SIMD
+    const int total2 = __hip_atomic_load(&n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    S1D_PHASE(2);
+#if T1D_S1_TRACE
+    if (ph && lane == 0) { ph[6] = total2; ph[7] = __hip_atomic_load(&n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); ph[8] = it; }
+#endif
     for (;;) {
-        const unsigned i = tile * kBlock + threadIdx.x;
-        __builtin_assume(i < (1u << 28));
-        Env<T> e;
-        T basal, bolus;
-        uint32_t meta;
-        // This tile's DMA must have landed.  vmcnt retires in order and the DMA is OLDER than everything the
-        // previous tile issued afterwards, of which at least kTileStores are unconditional stores
-        // (x[13], planned, last_qsto, last_food, last_cgm, prev_cgm, t, meta, cgm, bg, reward, done): once
-        // at most that many operations are outstanding the DMA is complete, and the wave does not sit
-        // through the write burst of its own stores.
-        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        unstage(a, st, e, basal, bolus, meta);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging area read out before it is refilled
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned ntile = tile + gridDim.x;
-        const bool more = ntile < ntiles;
-        const unsigned next_elem0 = ntile * kBlock + (unsigned)wave * 64u;
-        auto prefetch = [&]() {
-            if (more) stage_tile(a, next_elem0, st);      // in flight while this tile integrates
-        };
-        const uint32_t pid = T1D_META_PID(meta);
-        const T rp = prev_risk<MATH>(a, e.prev_cgm);
-        StepOut<T> o;
-        if (VARIANT == 2) {
-            const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
-            if (__ballot((int)pid != pid0) != 0ull) {
-                atomicOr(a.status, T1D_ST_BAD_LAYOUT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                break;                                   // no stores were issued: the counted wait above would not hold
-            }
-            ParsScalar<T> p;
-            p.load(a.dpar, kMaxPatients, pid0);
-            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
-            write_outputs<MATH>(a, i, e, o, rp);
-            store_env(a, i, pid, e);
-        } else if (VARIANT == 3) {
-            ParsReg<T> p;
-            p.load(lds, (int)pid);                       // 38 ds_reads per tile, then no LDS traffic in the RK4 loop
-            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
-            write_outputs<MATH>(a, i, e, o, rp);
-            store_env(a, i, pid, e);
-        } else {
-            ParsLds<T> p{lds, (int)pid};
-            o = step_body<MATH>(a, p, i, e, basal, bolus, a.bolus != nullptr, prefetch);
-            write_outputs<MATH>(a, i, e, o, rp);
-            store_env(a, i, pid, e);
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&taken2, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g * 64 >= total2) break;                        // wave-uniform
+        const int idx = g * 64 + (int)lane;
+        if (idx < total2) {
+            const unsigned i = (unsigned)list2[idx];
+            __builtin_assume(i < (1u << 28));
+            s1_chunk<DREG, T, STRIDE, EXTRA, 4>(a, ldp, lpr, lconst, i, S1NoLevel(), tr, 0);
         }
-        if (!more) break;
-        tile = ntile;
-        first = false;
     }
+    S1D_PHASE(3);
+    const int total1 = __hip_atomic_load(&n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&taken1, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g * 64 >= total1) break;                        // wave-uniform
+        const int idx = g * 64 + (int)lane;
+        if (idx < total1) {
+            const unsigned i = (unsigned)list1[idx];
+            __builtin_assume(i < (1u << 28));
+            s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoLevel(), tr, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    S1D_PHASE(4);
+#undef S1D_PHASE
 }
 
 // Rebuilds the CGM noise block of every env whose next sample(s) -- in minutes (t, t + minutes] -- start a
@@ -1060,7 +834,7 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
             prev = obs;
             integ += (obs - c.target) * st;
         }
-        o = step_body<MATH, T, P, NoHook, false, true, PR>(a, p, i, e, u, bolus, true, NoHook(), pr);
+        o = step_body<MATH, T, P, true, PR, VariantInfo<VARIANT>::tiered>(a, p, i, e, u, bolus, true, pr);
         obs = o.cgm;
         prev_meal = o.meal;
         if (c.bg_trace) c.bg_trace[(c.trace_row + s) * a.n + i] = o.bg;
@@ -1101,19 +875,13 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void rollout_pid_kernel(const KA
     const uint32_t pid = T1D_META_PID(meta);
     Env<T> e;
     load_env(a, i, meta, e);
-    if constexpr (VARIANT == 4 || VARIANT == 6) {
+    if constexpr (VARIANT == 4) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
-        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T, VI::adapt>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
-    } else if constexpr (VARIANT == 5 || VARIANT == 7) {
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+    } else if constexpr (VARIANT == 7) {
         ParsLds<T> p{lds, (int)pid};
-        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T, VI::adapt>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
-    } else if constexpr (VARIANT == 2) {
-        const int pid0 = __builtin_amdgcn_readfirstlane((int)pid);
-        if (__ballot((int)pid != pid0) != 0ull) { atomicOr(a.status, T1D_ST_BAD_LAYOUT); return; }
-        ParsScalar<T> p;
-        p.load(a.dpar, kMaxPatients, pid0);
-        rollout_body<VARIANT>(a, c, p, i, pid, e);
+        rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
     } else if constexpr (VARIANT == 3) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert hasattr(L, n), n
-    assert L.t1d_abi_version() == 1
+    assert L.t1d_abi_version() == 2
 
 
 def test_ctx_create_rejects_bad_arguments_without_touching_a_gpu():
@@ -102,20 +102,21 @@ def test_split_tables_match_independent_matrix_exponential(n_sub):
     names, tab = params.patient_table()
     dense = O.split_tables(tab, n_sub)
     dp = C.POINTER(C.c_double)
-    rows = 14 * n_sub + 21
+    nb = 2 * n_sub                                            # propagator blocks: tau = k / nb
+    rows = 14 * nb + 21
     c6, c8 = [4, 0, 1, 2, 3, 7, 8], [6, 5, 0, 1, 2, 3, 7]
     c5, c7 = [0, 1, 2, 3, 7], [5, 0, 1, 2, 3, 7]
     for ip in range(len(names)):
-        out = np.zeros(rows + 8)
+        out = np.zeros(rows + 12)
         row = np.ascontiguousarray(tab[ip])
         assert L.t1d_split_tables(row.ctypes.data_as(dp), 45, n_sub, out.ctypes.data_as(dp), len(out)) == 0
-        phi = dense[ip, :n_sub * 63].reshape(n_sub, 7, 9)
+        phi = dense[ip, :nb * 63].reshape(nb, 7, 9)
         want = np.zeros(rows)
         used = np.zeros((7, 9), bool)
-        for k in range(n_sub):
+        for k in range(nb):
             want[k * 14:k * 14 + 7] = phi[k, 4, c6]
             want[k * 14 + 7:k * 14 + 14] = phi[k, 6, c8]
-        t = 14 * n_sub
+        t = 14 * nb
         want[t:t + 5] = phi[-1, 0, c5]; want[t + 5:t + 10] = phi[-1, 1, c5]
         want[t + 10:t + 12] = phi[-1, 2, [2, 7]]; want[t + 12:t + 15] = phi[-1, 3, [2, 3, 7]]
         want[t + 15:t + 21] = phi[-1, 5, c7]
@@ -124,7 +125,8 @@ def test_split_tables_match_independent_matrix_exponential(n_sub):
         assert np.abs(phi[:, ~used]).max() < 1e-14            # what the layout drops is zero
         scale = np.maximum(np.abs(want), 1e-3)
         assert (np.abs(out[:rows] - want) / scale).max() < 1e-12, names[ip]
-        assert np.abs(out[rows:] - dense[ip, n_sub * 63:]).max() < 1e-14, names[ip]      # x2 weights for h and h/2
+        w = dense[ip, nb * 63:]                               # oracle order: gut step of level 0, 1, 2; library: 1, 2, 0
+        assert np.abs(out[rows:] - np.concatenate([w[4:8], w[8:12], w[0:4]])).max() < 1e-14, names[ip]
     bad = np.zeros(10)
     assert L.t1d_split_tables(np.ascontiguousarray(tab[0]).ctypes.data_as(dp), 45, 3, bad.ctypes.data_as(dp), 10) != 0
     assert L.t1d_split_tables(np.ascontiguousarray(tab[0]).ctypes.data_as(dp), 45, 4, bad.ctypes.data_as(dp), 10) != 0

@@ -3,19 +3,25 @@
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.ab_step import make  # noqa: E402
-from simglucose_amd import _lib  # noqa: E402
+from simglucose_amd import _lib, params, scenario_batch  # noqa: E402
+from simglucose_amd.batch_env import BatchedT1DSimEnv  # noqa: E402
 n = 1 << 20
-env, pool = make(n, "mod30", torch.float64, "Navigator", 4)
-env.set_option("integrator", 1); env.set_option("params_mode", int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+pid = np.arange(n) % 30
+env = BatchedT1DSimEnv(patient=pid, sensor="Navigator", n_sub=4, seed=1, extra_outputs=False)
+env.set_option("adaptive_gut", int(sys.argv[1]) if len(sys.argv) > 1 else 0)       # the trace marks live in step1_kernel
+mt, ma = scenario_batch.random_meal_tables(n, days=1, seed=5, device=env.device)
+env.set_meals(mt, ma); env.reset()
+_, tab = params.patient_table()
+b0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, device=env.device)
+pool = [(b0 * 2.0 * torch.rand(n, device=env.device, dtype=torch.float64)).contiguous() for _ in range(4)]
 for k in range(5):
     env.step(pool[k % 4])
 torch.cuda.synchronize()
-out = np.zeros(96 * 4 * 64, dtype=np.int64)
+out = np.zeros(128 * 4 * 64, dtype=np.int64)
 L = _lib.lib()
 L.t1d_debug_trace.argtypes = [C.c_void_p, C.c_void_p]
 assert L.t1d_debug_trace(env._ctx, out.ctypes.data_as(C.c_void_p)) == 0
-tr = out.reshape(96 * 4, 8, 8).astype(np.float64) * 0.01      # us (100 MHz)
+tr = out[:96 * 4 * 64].reshape(96 * 4, 8, 8).astype(np.float64) * 0.01      # us (100 MHz)
 t0 = tr[:, 0, 0].min()
 names = ["load wait", "prologue (pump, meal, eat, early stores)", "integration", "x stores issued + sensor loads arrive", "epilogue compute", "stores drain"]
 valid = tr[:, :, 6] > 0
