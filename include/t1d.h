@@ -78,9 +78,16 @@ enum {
 #define T1D_PUMP_NCOLS 6
 
 /* per-env packed integer word `meta`: bits 0-7 patient row, bit 8 "was eating last minute"
- * (t1dpatient.py:88,102 edge detector), bits 16-31 cursor into the meal table. */
+ * (t1dpatient.py:88,102 edge detector), bits 16-31 cursor into the meal table.  Bits 9-11 are a cache the
+ * one-minute kernels keep for themselves: bit 11 set = bits 9-10 hold the step-size level (0, 1, 2; see
+ * "adaptive_gut") of the env's NEXT minute, evaluated from the state and the meal table at the end of the previous
+ * launch.  A caller that writes the state, the clock or the meal table of an env itself clears bit 11 (every other
+ * library call does); a zero-initialised word says "not known". */
 #define T1D_META_PID(m)      ((m) & 0xffu)
 #define T1D_META_EATING      0x100u
+#define T1D_META_LEVEL(m)        (((m) >> 9) & 3u)
+#define T1D_META_LEVEL_KNOWN(m)  (((m) & 0x800u) != 0)
+#define T1D_META_LEVEL_BITS(lv)  (0x800u | ((lv) << 9))
 #define T1D_META_CURSOR(m)   ((m) >> 16)
 
 /* t1d_batch.flags; any other bit is rejected with T1D_E_INVALID */

@@ -152,8 +152,9 @@ class BatchedT1DSimEnv:
             raise ValueError("meal tables must both have shape [n_meals, n]")
         self.meal_time, self.meal_amt = mt, ma
         self._b.meal_time, self._b.meal_amt, self._b.n_meals = mt.data_ptr(), ma.data_ptr(), mt.shape[0]
-        # restart the table scan: cursor 0, next entry = row 0 (rows before the current minute are skipped lazily)
-        self.meta.bitwise_and_(0xFFFF)
+        # restart the table scan: cursor 0, next entry = row 0 (rows before the current minute are skipped lazily);
+        # bits 9-11 (the kernels' cached step-size level of the next minute, include/t1d.h) go with the old table
+        self.meta.bitwise_and_(0x1FF)
         self.next_meal.copy_(mt[0])
 
     def set_option(self, name, value):
@@ -347,6 +348,7 @@ class BatchedT1DSimEnv:
     def load_state_dict(self, sd):
         for k in _STATE_KEYS + ("cgm",):
             getattr(self, k).copy_(sd[k])
+        self.meta.bitwise_and_(~0xE00)          # the cached step-size level belongs to the meal table of the saved run
         self._clock = None
 
     def close(self):

@@ -497,16 +497,17 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
             const bool tiered = c->adaptive_gut != 0;
             // per-minute step sizes: lanes of levels 1 and 2 set aside and integrated together at the end of the launch
-            // (step1d_kernel) where level 0 exists (n_sub divisible by 4) and the two lists of the CU's envs fit next to
+            // (step1d_kernel) at n_sub = 4 (its unrolled integration) where the two lists of the CU's envs fit next to
             // the tables; adaptive_gut = 2 asks for the in-place form, 3 for the deferred form at any batch size
             const int per_block = (nchunks + blocks - 1) / blocks;
-            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * 2 * sizeof(int);
+            const size_t dyn1d = dyn1 + (size_t)(kS1DThreads / 64) * (b->dtype == T1D_F64 ? kParkBytes<double> : kParkBytes<float>) +
+                                 (size_t)per_block * 64 * 2 * sizeof(uint16_t);
             const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
-                               stride == 32 && !(n_sub & 3) && dyn1d + 512 <= (size_t)c->lds_per_block;
+                               stride == 32 && n_sub == 4 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
         hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
 #define T1D_LAUNCH_S1D(TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR>, dyn1d)); \
-        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR>), dim3(blocks), dim3(kS1Threads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR>), dim3(blocks), dim3(kS1DThreads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
 #define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \
                                else { if (extra) T1D_LAUNCH_S1(TT, ST, true, false); else T1D_LAUNCH_S1(TT, ST, false, false); } } while (0)
 #define T1D_S1D_BY(TT) do { const bool dreg = per_block < c->dreg_max_chunks; \

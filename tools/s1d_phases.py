@@ -32,6 +32,8 @@ names = ["start", "main pass done (wave)", "all chunks decided", "level-2 list d
 for k in range(5):
     v = t[:, :, k] - t0
     print("%-26s mean %7.2f  min %7.2f  max %7.2f us" % (names[k], v.mean(), v.min(), v.max()))
+print("%-26s mean %7.2f  min %7.2f  max %7.2f us" % ("kernel entry", (tr[:, :, 11] * 0.01 - t0).mean(), (tr[:, :, 11] * 0.01 - t0).min(), (tr[:, :, 11] * 0.01 - t0).max()))
+print("%-26s mean %7.2f  min %7.2f  max %7.2f us" % ("lists scanned (barrier)", (tr[:, :, 5] * 0.01 - t0).mean(), (tr[:, :, 5] * 0.01 - t0).min(), (tr[:, :, 5] * 0.01 - t0).max()))
 print("per workgroup: last wave out   mean %.2f max %.2f us" % ((t[:, :, 4].max(1) - t0).mean(), (t[:, :, 4].max() - t0)))
 print("level-2 list length per CU: mean %.1f max %d;  level-1: mean %.1f max %d;  chunks drawn per wave %d-%d" % (
     tr[:, 0, 6].mean(), tr[:, 0, 6].max(), tr[:, 0, 7].mean(), tr[:, 0, 7].max(), tr[:, :, 8].min(), tr[:, :, 8].max()))
@@ -49,3 +51,10 @@ for m in range(6):
     d = (ck[..., m + 1] - ck[..., m])[ok]
     print("%-42s mean %6.2f us  p10 %6.2f  p90 %6.2f" % (names[m], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
 print("whole chunk mean %.2f us over %d chunks" % ((ck[..., 6] - ck[..., 0])[ok].mean(), ok.sum()))
+
+good = ok & np.all(np.diff(ck[..., :7], axis=-1) >= 0, axis=-1)
+for k in range(6):
+    g = good[:, :, k]
+    if g.sum():
+        d = np.diff(ck[:, :, k, :7], axis=-1)[g]
+        print("chunk #%d of a wave (%4d): start %6.1f us after launch; " % (k, g.sum(), (ck[:, :, k, 0][g] - t0).mean()) + "  ".join("%5.2f" % v for v in d.mean(0)) + "  = %.2f us" % d.sum(1).mean())
