@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/sec of the fused T1D step on MI355X (BASELINE.json metric).
+"""bench.py -- env-steps/sec of the fused T1D step on MI355X, with the accuracy half of BASELINE.json's metric.
 
-One "step" = one pass of the hot path over the batch = ONE kernel launch advancing every env by
-one simulated minute (1-min dt: Navigator-class sensor, sample_time = 1).  Workload at N = 1:
-BASELINE.json configs[3]'s batch -- 1 048 576 concurrent envs, patient = i mod 30, random-action
-policy (basal = U(0,2) x the patient's steady-state basal, from a pool of pre-generated action
-tensors resident in HBM), per-env random meal tables, fp64, n_sub = 4 sub-steps per minute (the library's default
-"split" fixed-step integrator: exact insulin propagator + RK4 gut/glucose, same error vs SciPy as RK4(4) on all
-13 states -- DESIGN.md section 3; `--integrator rk4` times classical RK4; the gut sub-steps are halved in the
-minutes that cross a gastric-emptying transition fast unless `--fixed-step`), Philox CGM noise.
-With --gpus N each rank owns its own 1 Mi envs (weak scaling; independent episodes, no data-path
-collective); value = all ranks' env-steps / max-over-ranks wall time.
+One "step" = one pass of the hot path over the batch = ONE kernel launch advancing every env by one simulated
+minute (1-min dt: Navigator-class sensor, sample_time = 1).  Workload: BASELINE.json configs[3] -- 1 048 576
+concurrent envs, patient = i mod 30, random-action policy (basal = U(0,2) x the patient's steady-state basal, from a
+pool of pre-generated action tensors resident in HBM), per-env random meal tables with every episode starting at a
+random minute of the day, fp64, n_sub = 4 (the library's default integrator: the split scheme with per-minute step
+sizes, DESIGN.md sections 3-4; `--fixed-step` times level 1 in every minute, `--integrator rk4` classical RK4 on all
+13 states), Philox CGM noise.
+
+With --gpus N the 1 Mi envs are sharded over the N ranks (`--scaling strong`, the default: contiguous shards,
+env_offset = first global env of the shard, so every env's Philox stream and meal table are those of the one-GPU run;
+no data-path collective); `--scaling weak` gives every rank its own --envs instead.  value = all ranks' env-steps /
+max-over-ranks wall time of the K timed launches.
 
     python bench.py --gpus 1 --steps 1000 --warmup 400
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -27,15 +29,44 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES = {"f64": 352, "f32": 184}       # SURVEY.md §8(d): algorithmic HBM bytes per env-step
+METRIC = "env-steps/sec at batch=1M patients (1-min dt); fp64 glucose trace max-abs-err"     # BASELINE.json
+ALGO_BYTES = {"f64": 352, "f32": 184}       # SURVEY.md section 8(d): algorithmic HBM bytes per env-step
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # vector (non-MFMA) peaks; the fp32 figure counts packed FMAs
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
-def cpu_baseline(n_envs, steps, n_sub, sensor, integ="split"):
-    """The CPU oracle (oracle/t1d_oracle.c, a from-scratch port of the reference path with the same
-    RK4 integrator) timed on one host core over a bounded sample of the same workload."""
+def shard_range(n_total, rank, world):
+    """contiguous shards whose sizes differ by at most one (as simglucose_amd/distributed.py; restated here so that the
+    rank arithmetic of this file can be exercised without a GPU)"""
+    base, extra = divmod(int(n_total), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def plan_shard(envs, scaling, rank, world):
+    """-> (n_local, env_offset, n_global): what one rank simulates and where its envs sit in the global batch."""
+    if scaling == "strong":
+        lo, hi = shard_range(envs, rank, world)
+        return hi - lo, lo, envs
+    return envs, rank * envs, envs * world
+
+
+def refills_in(t0, n_steps, st, samples_per_block):
+    """launches of refill_kernel among steps t0 .. t0 + n_steps - 1 of a lock-step batch: one whenever the sample taken
+    at the end of the step opens a new 150-minute noise block (batch_env.py keeps the same clock)"""
+    cnt = 0
+    for k in range(n_steps):
+        t1 = (t0 + k + 1) * st
+        if (1 + t1 // st) % samples_per_block == 0:
+            cnt += 1
+    return cnt
+
+
+def _cpu_worker(args):
+    n_envs, steps, n_sub, sensor, integ, seed = args
     from oracle import t1d_oracle as O
-    rs = np.random.RandomState(0)
+    rs = np.random.RandomState(seed)
     pid = np.arange(n_envs) % 30
     env = O.OracleEnv(pid, sensor=sensor, normals=rs.randn(64, n_envs), integrator=integ, n_sub=n_sub)
     env.reset()
@@ -50,47 +81,115 @@ def cpu_baseline(n_envs, steps, n_sub, sensor, integ="split"):
         if k % 30 == 7:
             cho[0, (np.arange(n_envs) + k) % 5 == 0] = 50.0
         env.step(acts[k % 4], None, cho)
-    dt = time.perf_counter() - t0
-    return {"value": n_envs * steps * int(env.sample_time) / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d steps, %s integrator n_sub=%d (same scheme as the kernel), fp64, 1 thread, %.1f s" % (n_envs, steps, integ, n_sub, dt)}
+    return n_envs * steps * int(env.sample_time), time.perf_counter() - t0
 
 
-def main():
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n_envs, steps, n_sub, sensor, integ):
+    """The CPU oracle (oracle/t1d_oracle.c: a from-scratch C port of the reference path running the SAME integrator as the
+    kernel) timed on a bounded sample of the same workload: one host core, then every core this process may use."""
+    import multiprocessing as mp
+    done, dt = _cpu_worker((n_envs, steps, n_sub, sensor, integ, 0))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = {"value": done / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": "%d envs x %d steps, %s integrator n_sub=%d (same scheme as the kernel), fp64, 1 thread, %.1f s" % (n_envs, steps, integ, n_sub, dt),
+           "cpu_model": cpu_model(), "cpu_count": os.cpu_count()}
+    if cores > 1:
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(n_envs, steps, n_sub, sensor, integ, 1 + k) for k in range(cores)])
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env-steps/s", "cores": cores,
+                            "sample": "%d processes x (%d envs x %d steps), %.1f s wall incl. start-up" % (cores, n_envs, steps, wall)}
+    return out
+
+
+def accuracy_block(env, pool, mt, ma, integ, n_sub, sensor, minutes, n_sample, seed=1):
+    """The accuracy half of the metric on the bench's own workload, outside the timed region: `n_sample` envs spread over
+    the batch are replayed on the CPU oracle with the very normals, meals and actions the kernel used -- through the
+    SciPy-faithful DOPRI5 path (pinned to the reference's fixtures to ~1e-9) and through the oracle's restatement of the
+    kernel's own scheme."""
+    import torch
+    from oracle import t1d_oracle as O
+    n = env.n
+    rs = np.random.RandomState(seed)
+    sample = np.unique(np.concatenate([np.arange(0, min(64, n)), np.arange(max(n - 64, 0), n), rs.randint(0, n, n_sample)]))[:n_sample]
+    sidx = torch.as_tensor(sample, device=env.device)
+    st = env.minutes_per_step
+    K = minutes // st
+    z = env.philox_normals(1 + 10 * (2 + minutes // 150), draw0=0, episode=int(env.episode[0].item()) + 1)[:, sidx].cpu().numpy()
+    t_s, a_s = mt[:, sidx].cpu().numpy().astype(np.int64), ma[:, sidx].double().cpu().numpy()
+    cho = np.zeros((K * st, len(sample)))
+    for j in range(len(sample)):
+        for tt, aa in zip(t_s[:, j], a_s[:, j]):
+            if 0 <= tt < K * st:
+                cho[tt, j] = aa
+    pool_s = [p[sidx].double().cpu().numpy() for p in pool]
+    pid = env.patient_idx[sample]
+    ref = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="dopri")
+    same = O.OracleEnv(pid, sensor=sensor, normals=z, integrator=integ, n_sub=n_sub)
+    env.reset(); ref.reset(); same.reset()
+    worst_ref = np.zeros(len(sample)); worst_same = 0.0
+    for k in range(K):
+        env.step(pool[k % len(pool)])
+        r = ref.step(pool_s[k % len(pool)], None, cho[k * st:(k + 1) * st])
+        s = same.step(pool_s[k % len(pool)], None, cho[k * st:(k + 1) * st])
+        if k % 8 == 7 or k == K - 1:
+            bg = env.bg[sidx].double().cpu().numpy()
+            worst_ref = np.maximum(worst_ref, np.abs(bg - r["bg"]))
+            worst_same = max(worst_same, float(np.abs(bg - s["bg"]).max()))
+    return {"max_abs_err_mg_dl": float(worst_ref.max()), "p99_mg_dl": float(np.percentile(worst_ref, 99)),
+            "median_mg_dl": float(np.median(worst_ref)), "frac_envs_within_1e-3": float((worst_ref <= 1e-3).mean()),
+            "vs": "oracle DOPRI5 as SciPy drives it (rtol 1e-6; pinned to the reference's fixtures to ~1e-9)",
+            "hip_vs_oracle_same_scheme_max_mg_dl": worst_same,
+            "envs_sampled": int(len(sample)), "minutes": int(K * st), "quantity": "subcutaneous glucose (BG), per-env max over time"}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 1 000 timed launches behind 400 untimed ones (~0.13 s in all).  The first few hundred launches after an
-    # idle GPU run ~6 % slower whatever the integrator (clocks ramping: 87.7 us per launch with 20 warm-up launches,
-    # 82.3 with 400 and with 2 000, fixed steps), so a short warm-up measures the ramp, not the steady state.
+    # defaults: 1 000 timed launches behind 400 untimed ones (~0.15 s in all).  The first few hundred launches after an
+    # idle GPU run ~6 % slower whatever the integrator (clocks ramping), so a short warm-up measures the ramp.
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--prewarm", type=int, default=400,
                     help="launches ahead of the W warm-up steps that bring an idle GPU up to its running clocks (they advance the "
                          "same envs; reported in config.prewarm_launches)")
-    ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=1 << 20, help="envs of the whole job (--scaling strong) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--n-sub", type=int, default=4)
     ap.add_argument("--sensor", default="Navigator")
     ap.add_argument("--integrator", choices=("auto", "rk4", "split"), default="auto")
     ap.add_argument("--fixed-step", action="store_true",
-                    help="switch off the split integrator's adaptive gut refinement (the library default keeps it on: DESIGN.md section 4)")
+                    help="the split integrator at level 1 in every minute instead of per-minute step sizes (DESIGN.md section 4)")
     ap.add_argument("--midnight-start", action="store_true",
                     help="start every episode at 00:00 (default: a random minute of the day per env, like the reference's gym "
                          "wrapper draws a random start hour, so that every launch sees the day's mix of meal phases)")
     ap.add_argument("--in-place", action="store_true",
-                    help="adaptive refinement in place (adaptive_gut = 2) instead of deferred to the end of the launch")
+                    help="every lane takes its step-size level in place (adaptive_gut = 2) instead of levels 1 and 2 being set aside")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="t1d_ctx_set_option switches applied after the ones above (tuning runs), e.g. --opt dreg_max_chunks=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--accuracy-envs", type=int, default=256)
+    ap.add_argument("--accuracy-minutes", type=int, default=480)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
-    ap.add_argument("--cpu-envs", type=int, default=65536)
+    ap.add_argument("--cpu-envs", type=int, default=32768)
     ap.add_argument("--cpu-steps", type=int, default=600)
-    a = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from simglucose_amd.batch_env import BatchedT1DSimEnv
-    from simglucose_amd import params, scenario_batch
+    ap.add_argument("--plan-only", action="store_true", help="print this rank's shard plan as JSON and exit (no GPU; tests)")
+    a = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +198,23 @@ def main():
         print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus),
               file=sys.stderr)
         sys.exit(2)
+    n, env_offset, n_global = plan_shard(a.envs, a.scaling, rank, world)
+    if a.plan_only:
+        print(json.dumps({"rank": rank, "world": world, "n_local": n, "env_offset": env_offset, "n_global": n_global, "scaling": a.scaling}))
+        return
+
+    # the CPU baseline runs first: its all-core leg forks worker processes, which a process that has initialised the GPU
+    # should not do
+    integ_name = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else ("split" if a.fixed_step else "split_adaptive")
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_envs, a.cpu_steps, a.n_sub, a.sensor, integ_name)
+
+    import torch
+    import torch.distributed as dist
+    from simglucose_amd.batch_env import BatchedT1DSimEnv
+    from simglucose_amd import params, scenario_batch
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # T1D_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL init, barriers, max-reduce) with a single rank too:
@@ -119,28 +235,33 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    n = a.envs
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     names, tab = params.patient_table()
-    pid = np.arange(n, dtype=np.int64) % 30
+    pid = (env_offset + np.arange(n, dtype=np.int64)) % 30                  # patient of the GLOBAL env id
     env = BatchedT1DSimEnv(patient=pid, sensor=a.sensor, dtype=dt, device=dev, n_sub=a.n_sub, seed=1234,
-                           env_offset=rank * n, noise="philox", extra_outputs=False)
+                           env_offset=env_offset, noise="philox", extra_outputs=False)
     env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
-    integ = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else "split"
+    integ = integ_name
     env.set_option("adaptive_gut", 0 if a.fixed_step else (2 if a.in_place else 1))
-    if integ == "split" and not a.fixed_step:
-        integ = "split_adaptive"
     for kv in a.opt:
         name, value = kv.split("=")
         env.set_option(name, int(value))
-    days = 1 + (a.steps + a.warmup + a.prewarm) * env.minutes_per_step // 1440
-    gs = torch.Generator(device=dev); gs.manual_seed(99 + rank)
-    start_min = 0 if a.midnight_start else torch.randint(0, 1440, (n,), generator=gs, device=dev, dtype=torch.int32)
-    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=start_min, seed=1000, device=dev, dtype=dt, env_offset=rank * n)
+    st = env.minutes_per_step
+    days = 1 + max((a.steps + a.warmup + a.prewarm) * st, a.accuracy_minutes) // 1440
+    # per-env inputs as functions of the GLOBAL env id: the shards of an N-rank run are slices of the one-rank run
+    gs = torch.Generator(device="cpu"); gs.manual_seed(99)
+    start_all = torch.zeros(n_global, dtype=torch.int32) if a.midnight_start else torch.randint(0, 1440, (n_global,), generator=gs, dtype=torch.int32)
+    start_min = start_all[env_offset:env_offset + n].to(dev)
+    mt, ma = scenario_batch.random_meal_tables(n, days=days, start_minute_of_day=start_min, seed=1000, device=dev, dtype=dt, env_offset=env_offset)
     env.set_meals(mt, ma)
     basal0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, dtype=dt, device=dev)
-    g = torch.Generator(device=dev); g.manual_seed(7 + rank)
-    pool = [(basal0 * 2.0 * torch.rand(n, generator=g, device=dev, dtype=dt)).contiguous() for _ in range(8)]
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    pool = [(basal0 * 2.0 * torch.rand(n_global, generator=g, dtype=torch.float64)[env_offset:env_offset + n].to(dev, dt)).contiguous() for _ in range(8)]
+
+    accuracy = None
+    if rank == 0 and not a.no_accuracy:
+        accuracy = accuracy_block(env, pool, mt, ma, integ, a.n_sub, a.sensor, a.accuracy_minutes, a.accuracy_envs)
+        env.set_meals(mt, ma)            # restart the meal cursors for the timed episode
     env.reset()
     for k in range(a.prewarm + a.warmup):
         env.step(pool[k % 8])
@@ -168,48 +289,58 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     kern_ms = ev0.elapsed_time(ev1) / a.steps
-    minutes = env.minutes_per_step
-    total_env_steps = world * n * a.steps * minutes
+    total_env_steps = n_global * a.steps * st
     bg = env.bg
     sane = bool(torch.isfinite(bg).all()) and status == 0
 
     if rank == 0:
         tname = "double" if a.dtype == "f64" else "float"
-        if integ != "rk4" and minutes == 1:
-            kernel_name = {"split": "t1d::step1_kernel<%s, 32, false, false>",
-                           "split_adaptive": "t1d::step1_kernel<%s, 32, false, true>" if a.in_place
-                                             else "t1d::step1d_kernel<%s, false, false>"}[integ] % tname
+        if integ != "rk4" and st == 1:
+            kernel_name = {"split": "void t1d::step1_kernel<%s, 32, false, false>(t1d::KArgs<%s>, int)",
+                           "split_adaptive": "void t1d::step1_kernel<%s, 32, false, true>(t1d::KArgs<%s>, int)" if a.in_place
+                                             else "void t1d::step1d_kernel<%s, false, true>(t1d::KArgs<%s>, int)"}[integ] % (tname, tname)
         else:
-            kernel_name = "t1d::step_kernel<%d, %s, false>" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname)
-        traffic = a.traffic_bytes
-        if traffic is None:                               # last recorded PMC measurement of this exact configuration
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
-                    tj = json.load(f)
-                if (tj["envs"], tj["dtype"], tj["n_sub"], tj["minutes"], tj.get("integrator", "rk4"), tj.get("kernel", "")) == \
-                        (n, a.dtype, a.n_sub, minutes, integ, kernel_name):
-                    traffic = tj["traffic_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                traffic = None
-        algo = ALGO_BYTES[a.dtype] * n * minutes          # algorithmic bytes per launch (per GPU)
+            kernel_name = "void t1d::step_kernel<%d, %s, false>(t1d::KArgs<%s>)" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname, tname)
+        # last recorded PMC measurements of this exact configuration (tools/profile_bench.sh): HBM bytes, VALU instructions
+        traffic, valu_insts = a.traffic_bytes, None
+        try:
+            with open(os.path.join(PROFILE_DIR, "traffic.json")) as f:
+                tj = json.load(f)
+            if (tj["envs"], tj["dtype"], tj["n_sub"], tj["minutes"], tj.get("integrator"), tj.get("kernel")) == (n, a.dtype, a.n_sub, st, integ, kernel_name):
+                traffic = tj["traffic_bytes_per_launch"] if traffic is None else traffic
+                valu_insts = tj.get("valu_insts_per_launch")
+        except (OSError, KeyError, ValueError):
+            pass
+        algo = ALGO_BYTES[a.dtype] * n * st               # algorithmic bytes per launch (per GPU)
         ach = algo / (kern_ms * 1e-3) / 1e9
+        valu = None
+        if valu_insts:
+            # upper bound on the arithmetic rate: every vector instruction counted as one FMA on 64 lanes
+            tf = valu_insts * 64 * 2 / (kern_ms * 1e-3) / 1e12
+            valu = {"insts_per_env_step": valu_insts * 64 / (n * st), "achieved": tf, "peak": VALU_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
+                    "frac": tf / VALU_PEAK_TFLOPS[a.dtype], "note": "SQ_INSTS_VALU x 64 lanes x 2 flop (every vector instruction counted as an FMA): an upper bound"}
+        clock0 = a.prewarm + a.warmup
         out = {
-            "metric": "env-steps/sec at batch=1M patients (1-min dt)", "value": total_env_steps / wall,
+            "metric": METRIC, "value": total_env_steps / wall,
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "configs[3]: %d envs per GPU, patient=i mod 30, random-action policy, "
+            "config": {"workload": "configs[3]: %d envs in all (%d on this GPU), patient=i mod 30, random-action policy, "
                                    "random meal tables (episodes start at %s), %s sensor (sample_time %d min), %s integrator n_sub=%d, Philox CGM noise"
-                                   % (n, "00:00" if a.midnight_start else "a random minute of the day per env", a.sensor, minutes, integ, a.n_sub),
-                       "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": minutes, "prewarm_launches": a.prewarm, "parallelism": "env-shard x%d" % world},
+                                   % (n_global, n, "00:00" if a.midnight_start else "a random minute of the day per env", a.sensor, st, integ, a.n_sub),
+                       "envs_total": n_global, "envs_per_gpu": n, "n_sub": a.n_sub, "integrator": integ, "minutes_per_launch": st,
+                       "prewarm_launches": a.prewarm, "untimed_launches_before_timing": a.prewarm + a.warmup,
+                       "refill_kernel_launches_in_timed_region": refills_in(clock0, a.steps, st, int(150 // env.sample_time)),
+                       "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kernel_name,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype]},
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype], "valu": valu},
+            "accuracy": accuracy,
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_envs, a.cpu_steps, a.n_sub, a.sensor, integ)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

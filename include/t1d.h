@@ -17,6 +17,7 @@
  *                          t1d_ctx_set_option "integrator" / "adaptive_gut")
  *                       CGMSensor.measure / CGMNoise    simglucose/sensor/cgm.py:26-36, noise_gen.py:30-97
  *                       risk_index / risk_diff          simglucose/analysis/risk.py:5-17, env.py:27-33
+ *   t1d_model_rhs    <- T1DPatient.model               simglucose/patient/t1dpatient.py:119-208
  *   t1d_rollout_pid  <- SimObj.simulate loop with       simglucose/simulation/sim_engine.py:29-39
  *                       PIDController.policy            simglucose/controller/pid_ctrller.py:17-36
  *   t1d_rollout_bb   <- the same loop with BBController  simglucose/controller/basal_bolus_ctrller.py:34-80
@@ -78,16 +79,9 @@ enum {
 #define T1D_PUMP_NCOLS 6
 
 /* per-env packed integer word `meta`: bits 0-7 patient row, bit 8 "was eating last minute"
- * (t1dpatient.py:88,102 edge detector), bits 16-31 cursor into the meal table.  Bits 9-11 are a cache the
- * one-minute kernels keep for themselves: bit 11 set = bits 9-10 hold the step-size level (0, 1, 2; see
- * "adaptive_gut") of the env's NEXT minute, evaluated from the state and the meal table at the end of the previous
- * launch.  A caller that writes the state, the clock or the meal table of an env itself clears bit 11 (every other
- * library call does); a zero-initialised word says "not known". */
+ * (t1dpatient.py:88,102 edge detector), bits 16-31 cursor into the meal table. */
 #define T1D_META_PID(m)      ((m) & 0xffu)
 #define T1D_META_EATING      0x100u
-#define T1D_META_LEVEL(m)        (((m) >> 9) & 3u)
-#define T1D_META_LEVEL_KNOWN(m)  (((m) & 0x800u) != 0)
-#define T1D_META_LEVEL_BITS(lv)  (0x800u | ((lv) << 9))
 #define T1D_META_CURSOR(m)   ((m) >> 16)
 
 /* t1d_batch.flags; any other bit is rejected with T1D_E_INVALID */
@@ -289,6 +283,14 @@ int t1d_outcome_stats(int hip_device, int dtype, int64_t n, int64_t n_rows, cons
  * Lets a test replay a Philox run through the oracle. */
 int t1d_philox_normals(t1d_ctx* ctx, uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,
                        int32_t draw0, int32_t n_draws, double* out_device, void* hip_stream);
+
+/* T1DPatient.model (t1dpatient.py:119-208) for n independent points, one lane each: dxdt[k][i] = d x_k / dt at state
+ * x[13][n] for patient row pid[i] of the context's table, with cho[i] grams eaten in the minute (:121), insulin[i]
+ * U/min (:122; the pump is not applied) and the bookkeeping values last_qsto[i] (mg) / last_food[i] (g) behind Dbar
+ * (:130).  math = 0: ocml tanh and IEEE divisions as the reference writes them; 1: the arithmetic the step kernels use.
+ * All device arrays of `dtype`; pid int32 [n]. */
+int t1d_model_rhs(t1d_ctx* ctx, int dtype, int64_t n, int math, const void* x, const int32_t* pid, const void* cho,
+                  const void* insulin, const void* last_qsto, const void* last_food, void* dxdt, void* hip_stream);
 
 /* Wait for the stream and return the accumulated status bits through *status (then clear them). */
 int t1d_sync(t1d_ctx* ctx, void* hip_stream, int32_t* status);

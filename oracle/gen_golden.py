@@ -345,14 +345,43 @@ def g11_report():
     plt.close("all")
     # risk_index_trace (report.py:95-133) cannot be recorded here: with the installed pandas 2.3 / numpy 2.2 its
     # np.mean(DataFrame) yields a scalar and the function raises TypeError in pd.concat (an ordinary error of the
-    # reference under newer libraries).  Its formula is restated in the oracle and marked "parity unpinned".
+    # reference under newer libraries).  It is pinned by fixture G12 instead: the output files the reference holds.
     cols = ["BG>180", "BG<70", "70<=BG<=180", "BG>250", "BG<50"]
     save("g11_report.npz", bg=bg, percent=np.stack([p_stats[c].values for c in cols]),
          bg_min=np.asarray(bmin, float), bg_max=np.asarray(bmax, float),
          zones=np.array([pa, pb, pc, pd_, pe], float))
 
 
-ALL = {"G11": g11_report, "G1": g1_rhs, "G3": g3_pump, "G4": g4_sensor, "G5": g5_env, "G6": g6_config1,
+def g12_report_2017():
+    """G12: output files the reference itself holds (examples/results/2017-12-31_17-46-32: 30 patients x 24 h,
+    BBController, produced by the reference's authors with the library versions of the time): the BG column of every
+    per-patient <name>.csv (481 rows, 3-minute steps) as input, and what the reference's report functions wrote for
+    them -- risk_trace.csv (risk_index_trace: LBGI / HBGI per 60-row chunk, report.py:95-110), performance_stats.csv
+    (percent_stats + mean risk indices) and CVGA_stats.csv -- as expected outputs.  Data only: nothing is executed."""
+    import csv
+    d = os.path.join(REF, "examples", "results", "2017-12-31_17-46-32")
+    with open(os.path.join(d, "performance_stats.csv"), newline="") as f:
+        perf = list(csv.reader(f))
+    names = [r[0] for r in perf[1:]]
+    bg = []
+    for nm in names:
+        with open(os.path.join(d, nm + ".csv"), newline="") as f:
+            bg.append([float(r["BG"]) for r in csv.DictReader(f)])
+    bg = np.array(bg).T
+    with open(os.path.join(d, "risk_trace.csv"), newline="") as f:
+        rt = list(csv.reader(f))
+    tr = {(r[0], r[1]): [float(v) if v != "" else np.nan for v in r[2:]] for r in rt[1:]}
+    lbgi = np.array([tr[("LBGI", nm)] for nm in names]).T
+    hbgi = np.array([tr[("HBGI", nm)] for nm in names]).T
+    cols = perf[0][1:]
+    pstat = np.array([[float(v) for v in r[1:]] for r in perf[1:]])
+    with open(os.path.join(d, "CVGA_stats.csv"), newline="") as f:
+        cv = list(csv.reader(f))
+    save("g12_report_2017.npz", names=np.array(names), bg=bg, lbgi_trace=lbgi, hbgi_trace=hbgi,
+         perf_cols=np.array(cols), perf=pstat, cvga_zones=np.array([float(v) for v in cv[1][1:]]))
+
+
+ALL = {"G12": g12_report_2017, "G11": g11_report, "G1": g1_rhs, "G3": g3_pump, "G4": g4_sensor, "G5": g5_env, "G6": g6_config1,
        "G7": g7_upstream, "G8": g8_risk, "G9": g9_seeding, "G10": g10_pid}
 
 if __name__ == "__main__":

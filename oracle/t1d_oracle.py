@@ -430,16 +430,18 @@ def report_cvga(BG):
 
 
 def report_risk_index_trace(BG, chunk=60):
-    """risk_index_trace (analysis/report.py:95-110): per chunk of `chunk` rows and per env, f = mean over BG > 0 of
-    1.509 (ln(BG)^1.084 - 5.381); LBGI = 10 (f (f<0))^2, HBGI = 10 (f (f>0))^2 -> (LBGI, HBGI) each [n_chunks, envs].
-    PARITY UNPINNED: the reference function raises TypeError under the installed pandas 2.3 / numpy 2.2 (its
-    np.mean over a DataFrame no longer returns per-column means), so no fixture could be recorded; this restates
-    the formula with the per-column mean the code was written for."""
+    """risk_index_trace (analysis/report.py:95-110): per chunk of `chunk` rows and per env, f = mean of
+    1.509 (ln(BG)^1.084 - 5.381) over the rows where that is a number -- the reference masks BG <= 0 (`BG[BG > 0]` on a
+    DataFrame leaves NaN there), 0 < BG < 1 gives NaN through the power of a negative logarithm, and pandas' mean skips
+    NaN; LBGI = 10 (f (f<0))^2, HBGI = 10 (f (f>0))^2 -> (LBGI, HBGI) each [n_chunks, envs], NaN where a chunk has no
+    usable row.  Pinned by fixture G12 (the reference's own 2017 result files) to 1e-13."""
     BG = np.asarray(BG, dtype=np.float64)
     L, H = [], []
     for i in range(0, len(BG), chunk):
         c = BG[i:i + chunk]
         with np.errstate(invalid="ignore", divide="ignore"):
-            f = np.array([np.mean(1.509 * (np.log(col[col > 0]) ** 1.084 - 5.381)) for col in c.T])
+            v = 1.509 * (np.log(np.where(c > 0, c, np.nan)) ** 1.084 - 5.381)
+            cnt = (~np.isnan(v)).sum(0)
+            f = np.where(cnt > 0, np.nansum(v, 0) / np.maximum(cnt, 1), np.nan)
         L.append(10.0 * (f * (f < 0)) ** 2); H.append(10.0 * (f * (f > 0)) ** 2)
     return np.array(L), np.array(H)

@@ -22,7 +22,7 @@ META_EATING = 0x100
 
 EXPORTS = ("t1d_abi_version", "t1d_last_error", "t1d_ctx_create", "t1d_ctx_set_option", "t1d_ctx_destroy", "t1d_reset",
            "t1d_step", "t1d_rollout_pid", "t1d_philox_normals", "t1d_sync", "t1d_split_tables",
-           "t1d_rollout_bb", "t1d_random_meals", "t1d_outcome_stats")
+           "t1d_rollout_bb", "t1d_random_meals", "t1d_outcome_stats", "t1d_model_rhs")
 
 
 class T1DError(RuntimeError):
@@ -130,6 +130,7 @@ def lib():
     L.t1d_random_meals.argtypes = [C.c_int, u64, i64, i64, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
     L.t1d_outcome_stats.argtypes = [C.c_int, C.c_int, i64, i64, vp, C.POINTER(Outcome), vp]
     L.t1d_philox_normals.argtypes = [vp, u64, i64, i64, u32, i32, i32, vp, vp]
+    L.t1d_model_rhs.argtypes = [vp, C.c_int, i64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.t1d_sync.argtypes = [vp, vp, C.POINTER(i32)]
     L.t1d_split_tables.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int]
     for name in EXPORTS:

@@ -27,12 +27,17 @@ class BatchedT1DSimEnv:
     noise: "philox" draws the CGM noise normals in-kernel (rocRAND Philox4x32-10, stream =
            global env id); "host" reads them from ``normals[n_draws, n]`` (exact parity with
            ``numpy.random.RandomState(seed).randn()`` streams supplied by the caller).
+    cgm_history: keep the last hour of observations per env on the device -- the ``CGM_hist[-window:]`` that
+           ``T1DSimEnv.step`` hands to a custom ``reward_fun`` (simulation/env.py:100-102), window = 60 / sample_time
+           samples -- so that ``step(..., reward_fun=f)`` works on the batch: ``f(window)`` gets a ``[window, n]``
+           tensor, oldest sample first, NaN where an episode is younger than that, and returns ``[n]`` rewards.
+           Off by default: the fused default reward (risk_diff) needs only the previous sample.
     """
 
     def __init__(self, patient="adolescent#001", n_envs=None, sensor="Dexcom", pump="Insulet",
                  dtype=torch.float64, device="cuda:0", n_sub=4, seed=0, env_offset=0, noise="philox",
                  normals=None, random_init_bg=False, extra_outputs=True, sensor_row=None, pump_row=None,
-                 patient_table=None, use_pump=True, adaptive_gut=True):
+                 patient_table=None, use_pump=True, adaptive_gut=True, cgm_history=False):
         self._L = _lib.lib()                     # raises T1DError if the HIP extension is missing
         if not torch.cuda.is_available():
             raise _lib.T1DError("BatchedT1DSimEnv needs a ROCm GPU (torch.cuda.is_available() is False)")
@@ -123,6 +128,10 @@ class BatchedT1DSimEnv:
         self._closed = False
         self._clock = None         # minutes since the last FULL reset while every env shares one clock, else None
         self._flags0 = b.flags
+        self.window = int(60 / self.sample_time)            # samples a custom reward function sees (env.py:100)
+        self._hist = self._hist_pos = self._hist_cnt = None
+        if cgm_history:
+            self.enable_cgm_history()
 
     # ------------------------------------------------------------------ inputs
     def _as_input(self, v, buf):
@@ -152,9 +161,8 @@ class BatchedT1DSimEnv:
             raise ValueError("meal tables must both have shape [n_meals, n]")
         self.meal_time, self.meal_amt = mt, ma
         self._b.meal_time, self._b.meal_amt, self._b.n_meals = mt.data_ptr(), ma.data_ptr(), mt.shape[0]
-        # restart the table scan: cursor 0, next entry = row 0 (rows before the current minute are skipped lazily);
-        # bits 9-11 (the kernels' cached step-size level of the next minute, include/t1d.h) go with the old table
-        self.meta.bitwise_and_(0x1FF)
+        # restart the table scan: cursor 0, next entry = row 0 (rows before the current minute are skipped lazily)
+        self.meta.bitwise_and_(0xFFFF)
         self.next_meal.copy_(mt[0])
 
     def set_option(self, name, value):
@@ -164,6 +172,47 @@ class BatchedT1DSimEnv:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ CGM history for custom reward functions
+    def enable_cgm_history(self):
+        """allocate the per-env ring of the last `window` observations (call before reset())"""
+        if self._hist is None:
+            self._hist = torch.full((self.window, self.n), float("nan"), dtype=self.dtype, device=self.device)
+            self._hist_pos = torch.zeros(self.n, dtype=torch.int64, device=self.device)
+            self._hist_cnt = torch.zeros(self.n, dtype=torch.int64, device=self.device)
+
+    def _hist_reset(self, mask):
+        """T1DSimEnv._reset: CGM_hist = [sample #0] (env.py:126), which the reset kernel leaves in prev_cgm"""
+        if self._hist is None:
+            return
+        m = torch.ones(self.n, dtype=torch.bool, device=self.device) if mask is None else mask.bool()
+        self._hist[:, m] = float("nan")
+        self._hist_pos[m] = 0
+        self._hist_cnt[m] = 1
+        self._hist[0, m] = self.prev_cgm[m]
+
+    def _hist_push(self):
+        """CGM_hist.append(CGM) (env.py:94) for every env"""
+        self._hist_pos = (self._hist_pos + 1) % self.window
+        self._hist.scatter_(0, self._hist_pos.unsqueeze(0), self.cgm.unsqueeze(0))
+        self._hist_cnt = torch.clamp(self._hist_cnt + 1, max=self.window)
+
+    def _hist_after_rollout(self):
+        """a roll-out advances many steps inside one launch: what the ring holds afterwards is the last observation only"""
+        if self._hist is not None:
+            self._hist.fill_(float("nan"))
+            self._hist_pos.zero_()
+            self._hist_cnt.fill_(1)
+            self._hist[0] = self.cgm
+
+    def cgm_window(self):
+        """-> [window, n]: CGM_hist[-window:] of every env, oldest first, NaN-padded at the top while an episode has fewer
+        samples (the reference passes a shorter list then)."""
+        if self._hist is None:
+            raise _lib.T1DError("the CGM history is off: construct with cgm_history=True (or call enable_cgm_history() before reset())")
+        k = torch.arange(self.window, device=self.device).unsqueeze(1)
+        w = torch.gather(self._hist, 0, (self._hist_pos.unsqueeze(0) + 1 + k) % self.window)
+        return torch.where(k >= self.window - self._hist_cnt.unsqueeze(0), w, torch.full_like(w, float("nan")))
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, mask=None, x0=None):
@@ -186,11 +235,14 @@ class BatchedT1DSimEnv:
             _lib.check(self._L.t1d_reset(self._ctx, C.byref(b), mptr, int(self.random_init_bg), self._stream()))
         b.x0_override = None
         self._keep = (keep, mask)
+        self._hist_reset(mask)
         return self.cgm
 
-    def step(self, basal, bolus=None, cho=None, minutes=None):
+    def step(self, basal, bolus=None, cho=None, minutes=None, reward_fun=None):
         """One env.step for the whole batch: a single kernel launch advancing ``minutes``
-        (default int(sample_time)) with the action held.  -> (obs CGM [n], reward [n], done [n], info)."""
+        (default int(sample_time)) with the action held.  -> (obs CGM [n], reward [n], done [n], info).
+        reward_fun: None = the fused default, risk_diff (env.py:27-33); a callable gets ``cgm_window()`` -- the batch
+        form of ``reward_fun(CGM_hist[-window:])``, env.py:100-102 -- and returns the rewards [n] (needs cgm_history)."""
         b = self._b
         minutes = self.minutes_per_step if minutes is None else int(minutes)
         bas = self._as_input(basal, self._basal_buf)
@@ -219,6 +271,11 @@ class BatchedT1DSimEnv:
         if clock is not None:
             self._clock = clock + minutes
         self._keep = (bas, cho)
+        if self._hist is not None:
+            self._hist_push()
+        if reward_fun is not None:
+            reward = torch.as_tensor(reward_fun(self.cgm_window()), dtype=self.dtype, device=self.device).expand(self.n)
+            return self.cgm, reward, self.done, self.info()
         return self.cgm, self.reward, self.done, self.info()
 
     def info(self):
@@ -281,6 +338,7 @@ class BatchedT1DSimEnv:
                                                self.minutes_per_step, self.n_sub, self._stream()))
         if clock is not None:
             self._clock = clock + int(n_steps) * self.minutes_per_step
+        self._hist_after_rollout()
         return pid_state
 
     def bb_constants(self):
@@ -322,7 +380,26 @@ class BatchedT1DSimEnv:
                                               self.minutes_per_step, self.n_sub, self._stream()))
         if clock is not None:
             self._clock = clock + int(n_steps) * self.minutes_per_step
+        self._hist_after_rollout()
         return bb_state
+
+    def model_rhs(self, x, patient_idx, cho, insulin, last_qsto, last_food, math=1):
+        """T1DPatient.model (t1dpatient.py:119-208) at m independent points on the device: x [13, m], the others [m]
+        (cho grams eaten in the minute, insulin U/min as the model takes it, i.e. without the pump) -> dx/dt [13, m].
+        math = 0: ocml tanh / IEEE divisions as the reference writes them; 1: the step kernels' arithmetic."""
+        t = lambda v, dt=self.dtype: torch.as_tensor(v, dtype=dt).to(self.device).contiguous()
+        x = t(x); m = x.shape[1]
+        if x.shape[0] != 13:
+            raise ValueError("x must have shape [13, m]")
+        pid = t(patient_idx, torch.int32); args = [t(v) for v in (cho, insulin, last_qsto, last_food)]
+        if pid.shape != (m,) or any(v.shape != (m,) for v in args):
+            raise ValueError("patient_idx, cho, insulin, last_qsto, last_food must have m entries")
+        out = torch.empty(13, m, dtype=self.dtype, device=self.device)
+        p = lambda v: C.c_void_p(v.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.t1d_model_rhs(self._ctx, self._b.dtype, m, int(math), p(x), p(pid), p(args[0]), p(args[1]), p(args[2]),
+                                             p(args[3]), p(out), self._stream()))
+        return out
 
     def philox_normals(self, n_draws, draw0=0, episode=1):
         """The normals the kernels draw in Philox mode -> float64 [n_draws, n] (for replay tests)."""
@@ -343,12 +420,17 @@ class BatchedT1DSimEnv:
 
     # ------------------------------------------------------------------ checkpoint
     def state_dict(self):
-        return {k: getattr(self, k).clone() for k in _STATE_KEYS + ("cgm",)}
+        sd = {k: getattr(self, k).clone() for k in _STATE_KEYS + ("cgm",)}
+        if self._hist is not None:
+            sd.update({k: getattr(self, k).clone() for k in ("_hist", "_hist_pos", "_hist_cnt")})
+        return sd
 
     def load_state_dict(self, sd):
         for k in _STATE_KEYS + ("cgm",):
             getattr(self, k).copy_(sd[k])
-        self.meta.bitwise_and_(~0xE00)          # the cached step-size level belongs to the meal table of the saved run
+        for k in ("_hist", "_hist_pos", "_hist_cnt"):
+            if getattr(self, k) is not None and k in sd:
+                getattr(self, k).copy_(sd[k])
         self._clock = None
 
     def close(self):

@@ -40,7 +40,7 @@ struct t1d_ctx {
     double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
     int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of levels 1, 2 aside from this many chunks per CU up
-    int dreg_max_chunks = 32;        // ... and run the deferred passes with VGPR parameters below this many chunks per CU
+    int dreg_max_chunks = 65535;     // ... and run the list passes with VGPR parameters below this many chunks per CU
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
 };
@@ -500,8 +500,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             // (step1d_kernel) at n_sub = 4 (its unrolled integration) where the two lists of the CU's envs fit next to
             // the tables; adaptive_gut = 2 asks for the in-place form, 3 for the deferred form at any batch size
             const int per_block = (nchunks + blocks - 1) / blocks;
-            const size_t dyn1d = dyn1 + (size_t)(kS1DThreads / 64) * (b->dtype == T1D_F64 ? kParkBytes<double> : kParkBytes<float>) +
-                                 (size_t)per_block * 64 * 2 * sizeof(uint16_t);
+            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * 2 * sizeof(uint16_t);
             const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
                                stride == 32 && n_sub == 4 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
@@ -683,6 +682,24 @@ extern "C" int t1d_philox_normals(t1d_ctx* c, uint64_t seed, int64_t env_offset,
     T1D_HIP(hipSetDevice(c->device));
     hipLaunchKernelGGL(philox_normals_kernel, grid_for(n), dim3(kBlock), 0, (hipStream_t)stream, seed, env_offset, n,
                        episode, draw0, n_draws, out);
+    T1D_HIP(hipGetLastError());
+    return T1D_OK;
+}
+
+extern "C" int t1d_model_rhs(t1d_ctx* c, int dtype, int64_t n, int math, const void* x, const int32_t* pid, const void* cho,
+                             const void* insulin, const void* last_qsto, const void* last_food, void* dxdt, void* stream)
+{
+    if (!c || !x || !pid || !cho || !insulin || !last_qsto || !last_food || !dxdt) return fail(T1D_E_INVALID, "t1d_model_rhs: NULL argument");
+    if (n < 1 || n > (int64_t)1 << 28) return fail(T1D_E_INVALID, "t1d_model_rhs: n out of range");
+    if (dtype != T1D_F64 && dtype != T1D_F32) return fail(T1D_E_INVALID, "t1d_model_rhs: bad dtype");
+    if (math != 0 && math != 1) return fail(T1D_E_INVALID, "t1d_model_rhs: math must be 0 or 1");
+    T1D_HIP(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+#define T1D_RHS(M, TT, PAR) hipLaunchKernelGGL((rhs_kernel<M, TT>), grid_for(n), dim3(kBlock), 0, s, n, (const TT*)x, pid, (const TT*)cho, \
+                                               (const TT*)insulin, (const TT*)last_qsto, (const TT*)last_food, (TT*)dxdt, (const TT*)PAR)
+    if (dtype == T1D_F64) { if (math) T1D_RHS(1, double, c->d_par64); else T1D_RHS(0, double, c->d_par64); }
+    else { if (math) T1D_RHS(1, float, c->d_par32); else T1D_RHS(0, float, c->d_par32); }
+#undef T1D_RHS
     T1D_HIP(hipGetLastError());
     return T1D_OK;
 }

@@ -420,30 +420,6 @@ template <typename T, int STRIDE> struct ParsLdsS {
     __device__ __forceinline__ void pin() {}
     __device__ __forceinline__ void pin_split() {}
 };
-// the gut's parameters (read 8-64 times a minute, inside dependent chains) in VGPRs, the rest from the LDS table where
-// used (the glucose stages read theirs in one batch per stage): 8 register pairs instead of 20, a handful of LDS
-// round trips per minute instead of ~40
-template <typename T, int STRIDE, int LEVEL> struct ParsHybrid {
-    static constexpr bool kSplitRk4 = false;
-    const T* base; int pid;
-    T kmax, dk, ratc, cf, w0, w1, w2, w3;
-    __device__ __forceinline__ void load()
-    {
-        kmax = base[DP_KMAX * STRIDE + pid]; dk = base[DP_DK * STRIDE + pid]; ratc = base[DP_RATC * STRIDE + pid]; cf = base[DP_CF * STRIDE + pid];
-        w0 = base[kSplitW(LEVEL) * STRIDE + pid]; w1 = base[(kSplitW(LEVEL) + 1) * STRIDE + pid];
-        w2 = base[(kSplitW(LEVEL) + 2) * STRIDE + pid]; w3 = base[(kSplitW(LEVEL) + 3) * STRIDE + pid];
-        asm volatile("" : "+v"(kmax), "+v"(dk), "+v"(ratc), "+v"(cf), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
-    }
-    __device__ __forceinline__ T operator()(int idx) const
-    {
-        constexpr int W = kSplitW(LEVEL);
-        return idx == DP_KMAX ? kmax : idx == DP_DK ? dk : idx == DP_RATC ? ratc : idx == DP_CF ? cf :
-               idx == W ? w0 : idx == W + 1 ? w1 : idx == W + 2 ? w2 : idx == W + 3 ? w3 : base[idx * STRIDE + pid];
-    }
-    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(pid)); }
-    __device__ __forceinline__ void pin() {}
-    __device__ __forceinline__ void pin_split() {}
-};
 template <typename T, int STRIDE> struct PropLdsS {
     static constexpr bool kSplit = true;
     const T* base; int pid;
@@ -526,11 +502,11 @@ __device__ __forceinline__ int tier_level(P& p, const MinuteIn<T>& u, const T (&
     return l2 ? 2 : (calm ? 0 : 1);
 }
 
-// One minute at a given LEVEL.  HAVE_F1 / HAVE_K1: the caller has evaluated kgut_flux / the first glucose stage at the
-// start of the minute already (for the step-size rule) and hands them in.
-template <int LEVEL, typename T, typename P, typename PR, bool HAVE_F1 = false, bool HAVE_K1 = false>
-__device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0),
-                                            T k3_pre = T(0), T k4_pre = T(0), T k12_pre = T(0))
+// One minute at a given LEVEL.  HAVE_F1: the caller has evaluated kgut_flux at the start of the minute already (for the
+// step-size rule) and hands it in.  (Keeping the rule's first glucose stage as well costs three register pairs across
+// the gut steps: spills, measured slower.)
+template <int LEVEL, typename T, typename P, typename PR, bool HAVE_F1 = false>
+__device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0))
 {
     constexpr int GM = LEVEL == 2 ? 2 : 1;                      // gut steps per glucose half step
     constexpr int SB = LEVEL == 0 ? 4 : (LEVEL == 1 ? 2 : 1);   // propagator blocks per glucose half step
@@ -608,8 +584,7 @@ __device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T
         const bool hold = LEVEL != 0 && x3a < T(0);          // (level 0 is never chosen with x3 < 0)
         T z3 = x3a - cRa;
         T k3, k4, k12, a3, a4, a12;
-        if (HAVE_K1 && s == 0) { k3 = k3_pre; k4 = k4_pre; k12 = k12_pre; }
-        else glucose_rhs(p, z3, x4, x12, cRa, cDa, x6a, x8a, hold, x3a, k3, k4, k12);
+        glucose_rhs(p, z3, x4, x12, cRa, cDa, x6a, x8a, hold, x3a, k3, k4, k12);
         a3 = k3; a4 = k4; a12 = k12;
         glucose_rhs(p, z3 + h * k3, x4 + h * k4, x12 + h * k12, cRm, cDm, x6m, x8m, hold, x3a, k3, k4, k12);
         a3 += T(2) * k3; a4 += T(2) * k4; a12 += T(2) * k12;
@@ -632,120 +607,7 @@ __device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T
     x[7] = pr(t0 + 15) * s7 + pr(t0 + 16) * s5 + pr(t0 + 17) * s9 + pr(t0 + 18) * s10 + pr(t0 + 19) * s11 + pr(t0 + 20) * ui;
 }
 
-// split_level<0 / 1> for n_sub = 4 with the three parts run one after the other instead of interleaved: first every
-// propagated value the glucose stages will need and the new insulin states (which `store(k, value)` may write out at
-// once: they are dead from there on), then the gut steps, keeping c R and c R' at the glucose half steps, then the
-// glucose steps.  Same operations on the same operands as split_level -- but at no point are all three parts alive, which
-// is what lets a fourth wave share the SIMD (<= 128 VGPRs) in the single-minute kernel.  Everything is unrolled: the
-// few kept values live in registers under compile-time indices.
-struct NoStore { template <typename T> __device__ __forceinline__ void operator()(int, T) const {} };
-template <int LEVEL, typename T, typename P, typename PR, typename ST = NoStore>
-__device__ __forceinline__ void split_seq4(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], ST&& store = ST())
-{
-    static_assert(LEVEL == 0 || LEVEL == 1, "level 2 keeps the interleaved form (16 gut steps are not unrolled)");
-    constexpr int NH = LEVEL == 0 ? 2 : 4;                      // glucose half steps in the minute (n_sub = 4)
-    constexpr int NS = NH / 2, SB = 8 / NH, W = kSplitW(LEVEL);
-    const T h = T(1) / T(NH), H = h + h, H6 = H / T(6), hh = T(0.5) * h, h6 = h / T(6);
-    // (1) insulin: X = x6 and XL = x8 at every glucose half step, the new states at the end of the minute
-    T X6[NH + 1], X8[NH + 1];
-    {
-        const T s5 = x[5], s6 = x[6], s7 = x[7], s8 = x[8], s9 = x[9], s10 = x[10], s11 = x[11], ui = u.ins;
-        X6[0] = s6; X8[0] = s8;
-        // one table row (5-7 coefficients) at a time: all 49-77 at once would hold ~100 VGPRs for a few cycles
-#pragma unroll
-        for (int k = 1; k <= NH; ++k) {
-            const int r = (k * SB - 1) * 14;
-            {
-                T cf[7];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) cf[j] = pr(r + j);
-                X6[k] = cf[0] * s6 + cf[1] * s5 + cf[2] * s9 + cf[3] * s10 + cf[4] * s11 + cf[5] * ui + cf[6];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                T cf[7];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) cf[j] = pr(r + 7 + j);
-                X8[k] = cf[0] * s8 + cf[1] * s7 + cf[2] * s5 + cf[3] * s9 + cf[4] * s10 + cf[5] * s11 + cf[6] * ui;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        constexpr int t0 = 28 * 4;
-        auto dot5 = [&](int r) { T c[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) c[j] = pr(r + j);
-            return c[0] * s5 + c[1] * s9 + c[2] * s10 + c[3] * s11 + c[4] * ui; };
-        x[5] = dot5(t0);
-        __builtin_amdgcn_sched_barrier(0);
-        x[9] = dot5(t0 + 5);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            T c[11];
-#pragma unroll
-            for (int j = 0; j < 11; ++j) c[j] = pr(t0 + 10 + j);
-            x[10] = c[0] * s10 + c[1] * ui;
-            x[11] = c[2] * s10 + c[3] * s11 + c[4] * ui;
-            x[7] = c[5] * s7 + c[6] * s5 + c[7] * s9 + c[8] * s10 + c[9] * s11 + c[10] * ui;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        x[6] = X6[NH]; x[8] = X8[NH];
-        store(5, x[5]); store(9, x[9]); store(10, x[10]); store(11, x[11]); store(7, x[7]); store(6, x[6]); store(8, x[8]);
-    }
-    // (2) gut: RK4 on (x0, x1), x2 in exponential form, R = mass absorbed so far
-    T cR[NH + 1], cD[NH + 1];
-    {
-        T g0 = x[0], g1 = x[1], x2 = x[2], R = T(0);
-        cR[0] = T(0); cD[0] = p(DP_RATC) * x2;
-#pragma unroll
-        for (int k = 1; k <= NH; ++k) {
-            p.refresh();
-            const T kmax = p(DP_KMAX);
-            const T F1 = kgut_flux(p, u, g0, g1);
-            const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;
-            T y0 = g0 + hh * a0, y1 = g1 + hh * a1;
-            const T F2 = kgut_flux(p, u, y0, y1);
-            const T b0 = u.d_mg - kmax * y0, b1 = kmax * y0 - F2;
-            y0 = g0 + hh * b0; y1 = g1 + hh * b1;
-            const T F3 = kgut_flux(p, u, y0, y1);
-            const T c0 = u.d_mg - kmax * y0, c1 = kmax * y0 - F3;
-            y0 = g0 + h * c0; y1 = g1 + h * c1;
-            const T F4 = kgut_flux(p, u, y0, y1);
-            const T e0 = u.d_mg - kmax * y0, e1 = kmax * y0 - F4;
-            const T F23 = F2 + F3;
-            g0 += h6 * (a0 + T(2) * (b0 + c0) + e0);
-            g1 += h6 * (a1 + T(2) * (b1 + c1) + e1);
-            const T x2n = p(W) * x2 + p(W + 1) * F1 + p(W + 2) * (T(0.5) * F23) + p(W + 3) * F4;
-            R += (x2 - x2n) + h6 * (F1 + T(2) * F23 + F4);
-            x2 = x2n;
-            cR[k] = p(DP_CF) * R; cD[k] = p(DP_RATC) * x2;
-        }
-        x[0] = g0; x[1] = g1; x[2] = x2;
-        store(0, g0); store(1, g1); store(2, x2);
-    }
-    // (3) glucose: RK4 on (z3 = x3 - c R, x4, x12); x3 itself is carried from step to step
-    T x3a = x[3], x4 = x[4], x12 = x[12];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int ia = 2 * s, im = ia + 1, ib = ia + 2;
-        const bool hold = LEVEL != 0 && x3a < T(0);          // (level 0 is never chosen with x3 < 0)
-        T z3 = x3a - cR[ia];
-        T k3, k4, k12, a3, a4, a12;
-        glucose_rhs(p, z3, x4, x12, cR[ia], cD[ia], X6[ia], X8[ia], hold, x3a, k3, k4, k12);
-        a3 = k3; a4 = k4; a12 = k12;
-        glucose_rhs(p, z3 + h * k3, x4 + h * k4, x12 + h * k12, cR[im], cD[im], X6[im], X8[im], hold, x3a, k3, k4, k12);
-        a3 += T(2) * k3; a4 += T(2) * k4; a12 += T(2) * k12;
-        glucose_rhs(p, z3 + h * k3, x4 + h * k4, x12 + h * k12, cR[im], cD[im], X6[im], X8[im], hold, x3a, k3, k4, k12);
-        a3 += T(2) * k3; a4 += T(2) * k4; a12 += T(2) * k12;
-        glucose_rhs(p, z3 + H * k3, x4 + H * k4, x12 + H * k12, cR[ib], cD[ib], X6[ib], X8[ib], hold, x3a, k3, k4, k12);
-        z3 += H6 * (a3 + k3); x4 += H6 * (a4 + k4); x12 += H6 * (a12 + k12);
-        const T x3b = z3 + cR[ib];
-        x3a = hold ? x3a : (x3b < T(0) ? T(-1e-10) : x3b);
-    }
-    x[3] = x3a; x[4] = x4; x[12] = x12;
-    store(3, x3a); store(4, x4); store(12, x12);
-}
-
-// what the step-size rule needs at the start of the minute; F1 and the first glucose stage are reused by the integration
+// what the step-size rule needs at the start of the minute; F1 is reused by the integration
 template <typename T> struct TierPre { T f1, k3, k4, k12; int level; };
 template <typename T, typename P>
 __device__ __forceinline__ TierPre<T> tier_pre(P& p, const MinuteIn<T>& u, const T (&x)[13], int n_sub)

@@ -31,9 +31,6 @@
 #ifndef T1D_AB_FLAGS
 #define T1D_AB_FLAGS 0
 #endif
-#ifndef T1D_EXP
-#define T1D_EXP 0          // tuning builds: 64 = early groups at top priority, 8 = main pass with LDS parameters, 16 = interleaved integration in step1d_kernel, 32 = all parameters in VGPRs where REG
-#endif
 
 #include <climits>
 #include <cstdint>
@@ -518,29 +515,17 @@ constexpr int kS1DThreads = 256 * T1D_S1D_WAVES;      // step1d_kernel
 // One env-minute of one lane: everything between the chunk's loads and its last store.  MODE:
 //   0  level 1 for every lane (the fixed-step form of the scheme);
 //   1  step sizes by the rule, every lane its own level in place (split_minute_tiered);
-//   2  main pass of step1d_kernel: lanes of level 0 integrate; the others stop before anything of them is stored --
-//      those whose level the previous launch left in `meta` are in the launch's lists already, the rest are
-//      classified here and handed to on_level(level);
-//   3  pass of step1d_kernel over listed lanes of level 1;
+//   2  main pass of step1d_kernel: the rule is evaluated right after the meal bookkeeping and handed to
+//      on_level(level); lanes of level 0 integrate, the others stop there -- before anything of them is stored;
+//   3  pass of step1d_kernel over the listed lanes of level 1;
 //   4  ... of level 2.
-// Modes 2-4 (AHEAD): every word of the env is fetched by ONE round of loads at the top -- what the integration does
-// not need is parked in the wave's slot of LDS across it (`park`: [kParkRows][64] of T, then [kParkInts][64] ints)
-// instead of being fetched afterwards -- and the epilogue evaluates the step-size rule for the env's NEXT minute
-// (state after this one, the meal the table announces for t + 1; neither the action nor the noise enters the rule)
-// and leaves the level in `meta`, so that the next launch knows its lists before it starts.
-constexpr int kParkRows = 8, kParkInts = 4;
-template <typename T> constexpr int kParkBytes = (kParkRows * (int)sizeof(T) + kParkInts * 4) * 64;      // per wave
-
 template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONLEVEL>
-__device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, T* park, unsigned i, ONLEVEL&& on_level,
+__device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, ONLEVEL&& on_level,
                                          long long* tr, int tk)
 {
     constexpr int LEVEL = MODE == 2 ? 0 : (MODE == 4 ? 2 : 1);        // the level this pass integrates at (modes 0, 2, 3, 4)
-    constexpr bool AHEAD = MODE >= 2;
     (void)tr; (void)tk;
     S1_MARK(0);
-    const unsigned lane = threadIdx.x & 63u;
-    int* const parki = (int*)(park + kParkRows * 64);
     const BRows<T> X(a.x, a.n, kPackedRows);                // rows 0-12 x, 13 planned, 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_cgm, 18.. pts
     const BRows<int32_t> I(a.t, a.n, 3);                    // rows t, meta, next_meal
     const uint32_t meta = (uint32_t)(int32_t)at(I(1), i);
@@ -557,12 +542,6 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     e.cursor = (int)T1D_META_CURSOR(meta);
     const T basal = at(a.basal, i);
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
-    T prev_cgm = T(0);
-    if (AHEAD) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e.cur[k] = at(X(40 + k), i);
-        prev_cgm = at(X(17), i);
-    }
     S1_MARK(1);
     T q_basal, q_bolus;
     if (a.flags & T1D_BATCH_NO_PUMP) {
@@ -579,14 +558,12 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
     ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
     MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
+    T f1 = T(0);
     if (MODE == 2) {
-        // the level the previous launch left (not with dense CHO input: it assumed the meal table), else the rule now
-        int level;
-        const bool known = !a.cho && T1D_META_LEVEL_KNOWN(meta);
-        if (known) level = (int)T1D_META_LEVEL(meta);
-        else level = tier_pre(pl, u, e.x, a.n_sub).level;
-        on_level(known ? -1 : level);
-        if (level != 0) return;                      // nothing stored: a pass over its level's list redoes this lane from its loads
+        const TierPre<T> tp = tier_pre(pl, u, e.x, a.n_sub);
+        f1 = tp.f1;
+        on_level(tp.level);
+        if (tp.level != 0) return;                   // nothing stored: the pass over its level's list redoes this lane from its loads
     }
     // bookkeeping is final for this minute: store it now -- the meal words only where they changed (they do
     // while an env is eating, ~3 % of the minutes: 24 B per env-step of write traffic otherwise)
@@ -595,7 +572,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     if (e.lf != lf0) at(X(15), i) = e.lf;
     at(I(0), i) = e.t + 1;
     if (e.next_meal != e.next_meal_loaded) at(I(2), i) = e.next_meal;
-    if (!AHEAD) {   // patient id, eating flag, meal cursor: changes when a meal starts, ends or fires (no level left)
+    {   // patient id, eating flag, meal cursor: changes when a meal starts, ends or fires
         const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
         if (meta1 != meta) at(I(1), i) = (int32_t)meta1;
     }
@@ -603,65 +580,32 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         if (a.meal) at(a.meal, i) = meal;
         if (a.insulin) at(a.insulin, i) = insulin;
     }
-    if (AHEAD) {    // park what the epilogue needs; nothing of it stays in registers across the integration
-        park[0 * 64 + lane] = e.planned; park[1 * 64 + lane] = e.lq; park[2 * 64 + lane] = e.lf;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) park[(3 + k) * 64 + lane] = e.cur[k];
-        park[7 * 64 + lane] = prev_cgm;
-        parki[0 * 64 + lane] = e.t; parki[1 * 64 + lane] = (int)meta;
-        parki[2 * 64 + lane] = (e.cursor << 1) | (e.eating ? 1 : 0); parki[3 * 64 + lane] = e.next_meal;
-    }
     S1_MARK(2);
     if (!ab_flag(a, 0x800)) {
         PropLdsS<T, STRIDE> pr{lpr, (int)pid};
-        // AHEAD, levels 0 and 1 (n_sub = 4 there: t1d_step): the sub-systems one after the other, every final state value
-        // written out as soon as it exists
-        auto store_x = [&](int k, T v) { at(X(k), i) = v; };
-        constexpr bool SEQ = AHEAD && LEVEL < 2 && !(T1D_EXP & 16);
         if (MODE == 1) {
             split_minute_tiered(pl, pr, u, e.x, a.n_sub);
-        } else if (REG && (T1D_EXP & 32)) {
+        } else if (REG) {
             ParsReg<T> p;
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) p.v[kSplitW(LEVEL) + k] = pl(kSplitW(LEVEL) + k);
             p.pin_split();
-            if constexpr (SEQ) split_seq4<LEVEL>(p, pr, u, e.x, store_x);
-            else split_level<LEVEL>(p, pr, u, e.x, a.n_sub);
-        } else if (REG) {
-            ParsHybrid<T, STRIDE, LEVEL> p{ldp, (int)pid};
-            p.load();
-            if constexpr (SEQ) split_seq4<LEVEL>(p, pr, u, e.x, store_x);
-            else split_level<LEVEL>(p, pr, u, e.x, a.n_sub);
+            split_level<LEVEL, T, ParsReg<T>, decltype(pr), MODE == 2>(p, pr, u, e.x, a.n_sub, f1);
         } else {
-            if constexpr (SEQ) split_seq4<LEVEL>(pl, pr, u, e.x, store_x);
-            else split_level<LEVEL>(pl, pr, u, e.x, a.n_sub);
+            split_level<LEVEL, T, ParsLdsS<T, STRIDE>, decltype(pr), MODE == 2>(pl, pr, u, e.x, a.n_sub, f1);
         }
     }
     S1_MARK(3);
-    if (!(AHEAD && LEVEL < 2 && !(T1D_EXP & 16))) {
 #pragma unroll
-        for (int k = 0; k < 13; ++k) at(X(k), i) = e.x[k];
-    }
-    uint32_t meta0 = meta;
-    unsigned slot = lane;
-    if (AHEAD) {
-        // an opaque copy of the lane index, tied to the integration's result: the compiler can neither forward the
-        // parked values through registers nor move the reads ahead of the sub-step loops
-        asm volatile("" : "+v"(slot) : "v"(e.x[12]));
+    for (int k = 0; k < 13; ++k) at(X(k), i) = e.x[k];
+    // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e.cur[k] = park[(3 + k) * 64 + slot];
-        prev_cgm = park[7 * 64 + slot];
-        e.t = parki[0 * 64 + slot]; meta0 = (uint32_t)parki[1 * 64 + slot];
-    } else {
-        // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e.cur[k] = at(X(40 + k), i);
-        prev_cgm = at(X(17), i);
-    }
+    for (int k = 0; k < 4; ++k) e.cur[k] = at(X(40 + k), i);
     // with a 1-minute sensor every minute takes a fresh sample: the held value is never read
     T last_cgm = a.sen.st == 1 ? T(0) : (T)at(X(16), i);
+    const T prev_cgm = at(X(17), i);
     S1_MARK(4);
     bool due, entered = false;
     const T noise = measure_noise<false>(a, i, e, due, &entered);       // e.t is still the minute's start: sample for t + 1
@@ -679,7 +623,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         c = c > vmin ? c : vmin;
         c = c < vmax ? c : vmax;
         last_cgm = c;
-        if (a.sen.st != 1) at(X(16), i) = c;      // the zero-order hold is dead state with a 1-minute sensor
+        if (a.sen.st != 1) at(X(16), i) = c;                  // the zero-order hold is dead state with a 1-minute sensor
     }
     T l, h, r, rc = T(0);
     if (!ab_flag(a, 0x100)) risk_index1<1>(last_cgm, l, h, rc);
@@ -692,23 +636,6 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         if (a.lbgi) at(a.lbgi, i) = l;
         if (a.hbgi) at(a.hbgi, i) = h;
         if (a.risk) at(a.risk, i) = r;
-    }
-    if (AHEAD) {
-        // the step-size rule for this env's next minute, on the state just stored
-        const int ce = parki[2 * 64 + slot], next_meal = parki[3 * 64 + slot];
-        const int cursor = ce >> 1;
-        bool eating = (ce & 1) != 0;
-        uint32_t lv = 0;                                      // level not known (dense CHO input: the next meal is the caller's)
-        if (!a.cho) {
-            T planned = park[0 * 64 + slot], lq = park[1 * 64 + slot], lf = park[2 * 64 + slot];
-            T meal_next = T(0);
-            if (next_meal == e.t + 1 && cursor < a.n_meals) meal_next = at(rowv(a.meal_amt, a.n, cursor), i);
-            bool eat_next = eating;
-            const MinuteIn<T> un = eat_minute<1, T>(pl, e.x, meal_next, T(0), planned, lq, lf, eat_next);
-            lv = T1D_META_LEVEL_BITS((uint32_t)tier_pre(pl, un, e.x, a.n_sub).level);
-        }
-        const uint32_t meta1 = pid | (eating ? T1D_META_EATING : 0u) | lv | ((uint32_t)cursor << 16);
-        if (meta1 != meta0) at(I(1), i) = (int32_t)meta1;
     }
     if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
 #if T1D_S1_TRACE
@@ -788,25 +715,23 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         if ((int64_t)i >= a.n) continue;
         ++tk;
         s1_rotate_prio(it);
-        s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, (T*)nullptr, i, S1NoLevel(), tr, tk);
+        s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, S1NoLevel(), tr, tk);
     }
 }
 
 // The single-minute launch with per-minute step sizes.  Taken in place (step1_kernel<.., true>) a wave runs at the
 // highest level among its lanes: ~3 % of the env-minutes of random-meal days are at level 1 and ~1.4 % at level 2,
-// so almost every wave would pay for level 1 and half of them for level 2 (3.5 x level 1).  Here the main pass
-// integrates the lanes of level 0 -- half the arithmetic of level 1 -- and the lanes of the other levels are integrated
-// from lists in LDS, 64 at a time, every lane at the list's level.
-//   * The level of an env's minute is known before the launch: the previous launch evaluated the rule for it and left
-//     it in `meta` (s1_chunk).  The workgroup first scans the meta words of its chunks (4 B per env) into the two
-//     lists; its waves then take the listed groups first -- the long level 2 ahead of level 1 -- and the chunk queue
-//     after them, so the few long groups run next to the main pass instead of behind it (a lone level-2 group takes
-//     ~25 us, a third of the launch).
-//   * Lanes whose level is not in `meta` (first step after a reset or after any other kernel, dense CHO input) are
-//     classified in the main pass, set aside before anything of them is stored, and worked off after the queue.
-// The lists hold every env of the CU's share (t1d_step sizes them), so they cannot overflow; per-lane arithmetic is
-// that of the in-place form, lane for lane.
-// DREG: the list passes too take their parameters from VGPRs (t1d_step picks by chunks per CU).
+// so almost every wave would pay for level 1 and half of them for level 2 (3.5 x level 1): 185 us at 1 Mi envs.  Here
+// the main pass integrates the lanes of level 0 -- half the arithmetic of level 1 -- and a lane of another level only
+// leaves its env in that level's list in LDS (before anything of it is stored); waves that find the chunk queue empty
+// wait until every chunk of the CU is past that point and then take the listed envs 64 at a time, first the long
+// level 2, then level 1, from their loads, every lane at the list's level.  The lists hold every env of the CU's
+// share (t1d_step sizes them), so they cannot overflow; per-lane arithmetic is that of the in-place form, lane for lane.
+// (Tried and not kept -- git history: the level of an env's next minute evaluated at the end of the previous launch
+// and left in `meta`, so that the lists exist at launch start and are worked off next to the main pass: the gathers of
+// the listed envs then land in the cold first round of loads, 112 us instead of ~90.)
+// DREG: the list passes too take their parameters from VGPRs: they end the launch alone on their SIMDs, where LDS
+// round trips in the dependent chains count.
 template <typename T, bool EXTRA, bool DREG = false>
 __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
@@ -815,18 +740,13 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
     const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
     const unsigned lane = threadIdx.x & 63u;
-    const int wave = (int)(threadIdx.x >> 6);
-    T* const park = (T*)((char*)(lpr + a.prop_rows * STRIDE) + wave * kParkBytes<T>);     // this wave's slot
     // [per_block * 64] envs of level 1, as offsets from the workgroup's first env (< 65536: t1d_step), then those of level 2
-    uint16_t* const list1 = (uint16_t*)((char*)(lpr + a.prop_rows * STRIDE) + (kS1DThreads / 64) * kParkBytes<T>);
+    uint16_t* const list1 = (uint16_t*)(lpr + a.prop_rows * STRIDE);
     uint16_t* const list2 = list1 + per_block * 64;
-    __shared__ int queue, taken1, taken2, tail1, tail2, n1, n2, passed;
+    __shared__ int queue, taken1, taken2, n1, n2, passed;
     __shared__ T lconst[8];
-#if T1D_S1_TRACE
-    const long long t_entry = (long long)wall_clock64();
-#endif
     s1_stage_tables<T, STRIDE>(a, ldp, lpr, lconst);
-    if (threadIdx.x == 0) { queue = 0; taken1 = 0; taken2 = 0; tail1 = 0; tail2 = 0; n1 = 0; n2 = 0; passed = 0; }
+    if (threadIdx.x == 0) { queue = 0; taken1 = 0; taken2 = 0; n1 = 0; n2 = 0; passed = 0; }
     __syncthreads();
     const int first = (int)blockIdx.x * per_block;
     const int count = nchunks - first < per_block ? nchunks - first : per_block;
@@ -840,108 +760,63 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
 #define S1D_PHASE(k) do { } while (0)
 #endif
     S1D_PHASE(0);
-#if T1D_S1_TRACE
-    if (ph && lane == 0) ph[11] = t_entry;
-#endif
-    // the lists of the lanes whose level is in meta
-    if (!a.cho) {
-        for (int c = wave; c < count; c += kS1DThreads / 64) {
-            const unsigned i = (unsigned)(first + c) * 64u + lane;
-            __builtin_assume(i < (1u << 28));
-            if ((int64_t)i >= a.n) continue;
-            const uint32_t meta = (uint32_t)(int32_t)at(BRows<int32_t>(a.t, a.n, 3)(1), i);
-            if (!T1D_META_LEVEL_KNOWN(meta)) continue;
-            const uint32_t lv = T1D_META_LEVEL(meta);
-            if (lv == 1) list1[atomicAdd(&n1, 1)] = (uint16_t)(i - base);
-            else if (lv == 2) list2[atomicAdd(&n2, 1)] = (uint16_t)(i - base);
-        }
-    }
-    __syncthreads();
-    const int early2 = n2, early1 = n1;                     // what the lists hold before the main pass adds to them
-    S1D_PHASE(5);
     auto draw = [&](int* counter) -> int {
         int g = 0;
         if (lane == 0) g = atomicAdd(counter, 1);
         return __builtin_amdgcn_readfirstlane(g);
     };
-    // Work items of a wave, in this order: groups of up to 64 listed envs known at the start of the launch (level 2,
-    // then level 1), chunks of the queue, and -- once every chunk of the CU is past its decision point -- the groups
-    // the main pass added to the lists.  One loop, so that each of the three bodies exists once.
-    const int eg2 = (early2 + 63) >> 6, eg1 = (early1 + 63) >> 6;       // groups known at the start
-    bool more2 = eg2 > 0, more1 = eg1 > 0, drained = false;
-    int total2 = early2, total1 = early1;
-    for (int it = 0;; ++it) {
-        int kind = -1, lo = 0, hi = 0;                      // wave-uniform
-        if (more2) {
-            const int g = draw(&taken2);
-            if (g < eg2) { kind = 2; lo = g * 64; hi = lo + 64 < early2 ? lo + 64 : early2; } else more2 = false;
-        }
-        if (kind < 0 && more1) {
-            const int g = draw(&taken1);
-            if (g < eg1) { kind = 1; lo = g * 64; hi = lo + 64 < early1 ? lo + 64 : early1; } else more1 = false;
-        }
-        if (kind < 0 && !drained) {
-            const int c = draw(&queue);
-            if (c < count) { kind = 0; lo = c; }
-            else {
-                drained = true;
-                S1D_PHASE(1);
-                // every chunk of this CU has been drawn; those still in flight may yet add to the lists
-                while (__hip_atomic_load(&passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < count) __builtin_amdgcn_s_sleep(4);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                total2 = __hip_atomic_load(&n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                total1 = __hip_atomic_load(&n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                S1D_PHASE(2);
+    int it = 0;
+    for (;; ++it) {
+        const int c = draw(&queue);
+        if (c >= count) break;                              // wave-uniform
+        const unsigned i = (unsigned)(first + c) * 64u + lane;
+        __builtin_assume(i < (1u << 28));
+        s1_rotate_prio(it);
+        if ((int64_t)i < a.n) {
 #if T1D_S1_TRACE
-                if (ph && lane == 0) { ph[6] = total2; ph[7] = total1; ph[8] = it; ph[9] = early2; ph[10] = early1; }
+            tr = ph ? ph + 16 : nullptr;                    // per-chunk phase marks of the wave's first six chunks
 #endif
-            }
+            s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, [&](int level) {
+                if (level == 1) list1[atomicAdd(&n1, 1)] = (uint16_t)(i - base);
+                else if (level == 2) list2[atomicAdd(&n2, 1)] = (uint16_t)(i - base);
+                // lane 0 of a chunk is always a live env: it reports the chunk past its decision point, after the
+                // list entries of the wave (LDS operations of one wave execute in order)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicAdd(&passed, 1);
+            }, tr, it);
         }
-        if (kind < 0) {                                     // drained: what the main pass added
-            lo = early2 + draw(&tail2) * 64;
-            if (lo < total2) { kind = 2; hi = lo + 64 < total2 ? lo + 64 : total2; }
-            else {
-                lo = early1 + draw(&tail1) * 64;
-                if (lo < total1) { kind = 1; hi = lo + 64 < total1 ? lo + 64 : total1; }
-                else break;
-            }
-        }
-        if (kind == 0) {
-            const unsigned i = (unsigned)(first + lo) * 64u + lane;
+    }
+    tr = nullptr;
+    S1D_PHASE(1);
+    // every chunk of this CU has been drawn; those still in flight may yet add to the lists
+    while (__hip_atomic_load(&passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < count) __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_s_setprio(3);                          // the launch ends with these passes: they go first on their SIMD
+    const int total2 = __hip_atomic_load(&n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int total1 = __hip_atomic_load(&n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    S1D_PHASE(2);
+#if T1D_S1_TRACE
+    if (ph && lane == 0) { ph[6] = total2; ph[7] = total1; ph[8] = it; }
+#endif
+    for (;;) {
+        const int lo = draw(&taken2) * 64;
+        if (lo >= total2) break;                            // wave-uniform
+        if (lo + (int)lane < total2) {
+            const unsigned i = base + (unsigned)list2[lo + (int)lane];
             __builtin_assume(i < (1u << 28));
-            s1_rotate_prio(it);
-            if ((int64_t)i < a.n) {
-#if T1D_S1_TRACE
-                tr = ph ? ph + 16 : nullptr;                // per-chunk phase marks of the wave's first six chunks
-#endif
-                s1_chunk<!(T1D_EXP & 8), T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, park, i, [&](int level) {
-                    if (level == 1) list1[atomicAdd(&n1, 1)] = (uint16_t)(i - base);
-                    else if (level == 2) list2[atomicAdd(&n2, 1)] = (uint16_t)(i - base);
-                    // lane 0 of a chunk is always a live env: it reports the chunk past its decision point, after the
-                    // list entries of the wave (LDS operations of one wave execute in order)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) atomicAdd(&passed, 1);
-                }, tr, it);
-            }
-        } else {
-            // groups known at the start run next to the main pass at the lowest priority (they have the whole launch);
-            // what is left after the queue goes first
-            if ((T1D_EXP & 64) || drained) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            const int idx = lo + (int)lane;
-            if (idx < hi) {
-                if ((T1D_EXP & 128)) { } else if (kind == 2) {
-                    const unsigned i = base + (unsigned)list2[idx];
-                    __builtin_assume(i < (1u << 28));
-                    s1_chunk<DREG, T, STRIDE, EXTRA, 4>(a, ldp, lpr, lconst, park, i, S1NoLevel(), nullptr, 0);
-                } else {
-                    const unsigned i = base + (unsigned)list1[idx];
-                    __builtin_assume(i < (1u << 28));
-                    s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, park, i, S1NoLevel(), nullptr, 0);
-                }
-            }
+            s1_chunk<DREG, T, STRIDE, EXTRA, 4>(a, ldp, lpr, lconst, i, S1NoLevel(), nullptr, 0);
         }
     }
     S1D_PHASE(3);
+    for (;;) {
+        const int lo = draw(&taken1) * 64;
+        if (lo >= total1) break;                            // wave-uniform
+        if (lo + (int)lane < total1) {
+            const unsigned i = base + (unsigned)list1[lo + (int)lane];
+            __builtin_assume(i < (1u << 28));
+            s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoLevel(), nullptr, 0);
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0x0070);
     S1D_PHASE(4);
 #undef S1D_PHASE
@@ -1116,6 +991,42 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
     if (a.insulin) at(a.insulin, i) = T(0);
 }
 
+// T1DPatient.model at n independent points (t1d_model_rhs): the RHS of the step kernels, on its own
+template <int MATH, typename T>
+__global__ __launch_bounds__(kBlock) void rhs_kernel(int64_t n, const T* x, const int32_t* pid, const T* cho, const T* ins,
+                                                     const T* lq, const T* lf, T* out, const T* dpar)
+{
+    __shared__ T lds[DP_RK4_COUNT * kMaxPatients];
+    for (int j = threadIdx.x; j < DP_RK4_COUNT * kMaxPatients; j += blockDim.x) lds[j] = dpar[j];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    ParsLds<T> p{lds, pid[i]};
+    T xs[13], k[13];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) xs[j] = x[j * n + i];
+    // the per-minute inputs exactly as eat_minute forms them (t1dpatient.py:121-122,130,136-140)
+    MinuteIn<T> u;
+    u.d_mg = cho[i] * T(1000);
+    u.ins = ins[i] * p(DP_INSC);
+    const T dbar = lq[i] + lf[i] * T(1000);
+    u.has_dbar = dbar > T(0);
+    const T dsafe = u.has_dbar ? dbar : T(1);
+    if (MATH == 0) {
+        u.aa = u.has_dbar ? p(DP_CAA) / dsafe : T(0);
+        u.cc = u.has_dbar ? p(DP_CCC) / dsafe : T(0);
+    } else {
+        const T inv2 = u.has_dbar ? fdiv(T(2), dsafe) : T(0);
+        u.aa = p(DP_CAA) * inv2;
+        u.cc = p(DP_CCC) * inv2;
+    }
+    u.bD = p(DP_B) * dsafe; u.dD = p(DP_D) * dsafe;
+    u.aabD = u.aa * u.bD; u.ccdD = u.cc * u.dD;
+    rhs<MATH>(p, u, xs, k);
+#pragma unroll
+    for (int j = 0; j < 13; ++j) out[j * n + i] = k[j];
+}
+
 __global__ void philox_normals_kernel(uint64_t seed, int64_t env_offset, int64_t n, uint32_t episode,
                                       int draw0, int n_draws, double* out)
 {
@@ -1250,7 +1161,10 @@ __global__ __launch_bounds__(kBlock) void outcome_kernel(int64_t n, int64_t rows
             const T bg = tr[r * n + i];
             c180 += bg > T(180); c70 += bg < T(70); cin += (bg >= T(70)) & (bg <= T(180)); c250 += bg > T(250); c50 += bg < T(50);
             if (risk_trace) {
-                if (bg > T(0)) { fsum += 1.509 * (pow(log((double)bg), 1.084) - 5.381); ++fcnt; }      // report.py:98-100
+                if (bg > T(0)) {                                                           // report.py:98-100: BG[BG > 0], and
+                    const double fv = 1.509 * (pow(log((double)bg), 1.084) - 5.381);      // pandas' mean skips the NaN that
+                    if (fv == fv) { fsum += fv; ++fcnt; }                                  // 0 < BG < 1 gives (negative log ^ 1.084)
+                }
                 if ((r + 1) % chunk == 0 || r == rows - 1) {
                     const double f = fcnt ? fsum / (double)fcnt : __builtin_nan("");
                     const double fl = f < 0.0 ? f : 0.0, fh = f > 0.0 ? f : 0.0;                        // report.py:104-105

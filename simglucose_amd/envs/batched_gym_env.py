@@ -25,16 +25,19 @@ class BatchedGymT1DSimEnv(object):
     INSULIN_PUMP_HARDWARE = "Insulet"
 
     def __init__(self, n_envs, patient_name="adolescent#001", seed=0, device="cuda:0", dtype=torch.float64,
-                 exact=False, auto_reset=False, horizon_days=2, n_sub=4, env_offset=0):
+                 exact=False, auto_reset=False, horizon_days=2, n_sub=4, env_offset=0, reward_fun=None):
         self.n = int(n_envs)
         names = [patient_name] * self.n if isinstance(patient_name, str) else list(patient_name)
         self.patient_names = names
         self.seed_value, self.exact, self.auto_reset = int(seed), bool(exact), bool(auto_reset)
         self.horizon_days = int(horizon_days)
+        # as the reference wrapper's reward_fun (simglucose_gym_env.py:27-46), for the batch: f(window [20, n]) -> [n]
+        self.reward_fun = reward_fun
         self._episode = 0
         self.env = BatchedT1DSimEnv(patient=names, sensor=self.SENSOR_HARDWARE, pump=self.INSULIN_PUMP_HARDWARE,
                                     dtype=dtype, device=device, n_sub=n_sub, seed=self.seed_value,
-                                    env_offset=env_offset, noise="philox", random_init_bg=not exact)
+                                    env_offset=env_offset, noise="philox", random_init_bg=not exact,
+                                    cgm_history=reward_fun is not None)
         self.start_hour = torch.zeros(self.n, dtype=torch.int64, device=self.env.device)
         self.max_basal = float(self.env.pump_row[4])
 
@@ -71,16 +74,26 @@ class BatchedGymT1DSimEnv(object):
         self.start_hour = torch.as_tensor(hours, device=self.env.device)
         return x0
 
+    def _start_hours(self):
+        """start hour of every env of this episode, a function of (seed, episode, GLOBAL env id) only -- splitmix64 of the
+        id, keyed -- so that the shards of a multi-GPU job draw what the slices of one big batch would"""
+        gid = torch.arange(self.n, dtype=torch.int64, device=self.env.device) + int(self.env.env_offset)
+        lsr = lambda v, s: (v >> s) & ((1 << (64 - s)) - 1)               # logical shift on two's-complement int64
+        wrap = lambda c: c - (1 << 64) if c >= (1 << 63) else c
+        z = gid * wrap(0x9E3779B97F4A7C15) + wrap((self.seed_value * 1000003 + self._episode) & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ lsr(z, 30)) * wrap(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * wrap(0x94D049BB133111EB)
+        z = z ^ lsr(z, 31)
+        return lsr(z, 11) % 24
+
     def _build_device(self, mask=None):
-        g = torch.Generator(device=self.env.device)
-        g.manual_seed(self.seed_value * 1000003 + self._episode)
-        hours = torch.randint(0, 24, (self.n,), generator=g, device=self.env.device)
+        hours = self._start_hours()
         if mask is not None:
             hours = torch.where(mask.bool(), hours, self.start_hour)
         self.start_hour = hours
         mt, ma = scenario_batch.random_meal_tables(self.n, days=self.horizon_days, start_minute_of_day=hours * 60,
                                                    seed=self.seed_value * 7919 + self._episode, device=self.env.device,
-                                                   dtype=self.env.dtype)
+                                                   dtype=self.env.dtype, env_offset=self.env.env_offset)
         if mask is not None and self.env.meal_time is not None and self.env.meal_time.shape == mt.shape:
             keep = ~mask.bool()
             mt[:, keep] = self.env.meal_time[:, keep]; ma[:, keep] = self.env.meal_amt[:, keep]
@@ -117,7 +130,7 @@ class BatchedGymT1DSimEnv(object):
         a = torch.as_tensor(action, dtype=self.env.dtype, device=self.env.device).reshape(-1)
         if a.numel() == 1:
             a = a.expand(self.n)
-        obs, reward, done, info = self.env.step(a.contiguous())
+        obs, reward, done, info = self.env.step(a.contiguous(), reward_fun=self.reward_fun)
         done_b = done.bool()
         if self.auto_reset and not self.exact and bool(done_b.any()):
             info = dict(info, terminal_observation=obs.clone())

@@ -97,6 +97,25 @@ class T1DPatient(Patient):
             raise RuntimeError("this patient is driven by its T1DSimEnv; call env.step")
         env.step(float(action.insulin), cho=np.full((1, 1), float(action.CHO)), minutes=1)
 
+    @staticmethod
+    def model(t, x, action, params, last_Qsto, last_foodtaken):
+        """dx/dt of the 13-state model (reference: the static T1DPatient.model, t1dpatient.py:119-208), evaluated on the
+        device through t1d_model_rhs with the reference's own arithmetic (ocml tanh, IEEE divisions).  `params` is a row of
+        vpatient_params.csv (pandas Series); `action` has .CHO (g eaten this minute) and .insulin (U/min)."""
+        from ..batch_env import BatchedT1DSimEnv
+        row = np.empty(13 + len(_params.MODEL_COLS))
+        row[:13] = np.asarray(params.iloc[2:15], dtype=np.float64)
+        row[13:] = [float(params[c]) for c in _params.MODEL_COLS]
+        key = row.tobytes()
+        env = T1DPatient._model_envs.get(key)
+        if env is None:
+            env = T1DPatient._model_envs[key] = BatchedT1DSimEnv(patient="custom", n_envs=1, patient_table=row, sensor="Navigator")
+        out = env.model_rhs(np.asarray(x, dtype=np.float64).reshape(13, 1), [0], [float(action.CHO)], [float(action.insulin)],
+                            [float(last_Qsto)], [float(last_foodtaken)], math=0)
+        return out[:, 0].cpu().numpy()
+
+    _model_envs = {}
+
     # ---------------------------------------------------------------- reset
     @property
     def seed(self):

@@ -176,3 +176,81 @@ def test_batched_gym_env_device_mode_and_auto_reset():
     assert int(env.env.t.min()) < 600 and int(env.env.t.max()) == 600
     assert int(env.env.episode.max()) >= 2
     assert env.env.sync() == 0
+
+
+def test_batched_reward_fun_equals_single_env_adapters():
+    """Custom reward functions on the batch (reference: T1DSimEnv.step(action, reward_fun) hands the function the last
+    hour of CGM_hist, simulation/env.py:100-102; rule of examples/custom_reward_function.py:5-14 and
+    tests/test_reward_fun.py:6-12, plus one that uses the whole window): N envs of the batched env give what N
+    single-env adapters give, step by step -- rewards, observations and the window itself, incl. the first steps
+    of an episode, where the history is shorter than an hour, and across a reset."""
+    import torch
+    from simglucose_amd.batch_env import BatchedT1DSimEnv
+    from simglucose_amd.envs import BatchedGymT1DSimEnv
+    from simglucose_amd.simulation.env import T1DSimEnv
+    from simglucose_amd.controller.base import Action
+    from simglucose_amd.sensor.cgm import CGMSensor
+    from simglucose_amd.actuator.pump import InsulinPump
+    from simglucose_amd.patient.t1dpatient import T1DPatient
+    from simglucose_amd.simulation.scenario import CustomScenario
+
+    def custom_reward(BG_last_hour):                                   # the reference's example rule
+        if BG_last_hour[-1] > 180:
+            return -1
+        elif BG_last_hour[-1] < 70:
+            return -2
+        return 1
+
+    def mean_drop(BG_last_hour):                                       # uses the whole window
+        return float(BG_last_hour[0] - np.mean(BG_last_hour))
+
+    def custom_reward_b(w):
+        return torch.where(w[-1] > 180, -1.0, torch.where(w[-1] < 70, -2.0, 1.0))
+
+    def mean_drop_b(w):
+        first = torch.gather(w, 0, torch.isnan(w).sum(0, keepdim=True).clamp(max=w.shape[0] - 1))[0]    # oldest valid sample
+        return first - torch.nanmean(w, 0)
+
+    names = ["adolescent#003", "adult#002", "child#006"]
+    seeds = [3, 8, 21]
+    t0 = datetime(2018, 1, 1, 6, 0, 0)
+    scen = [(0.5, 45), (1.5, 20)]
+    K, st = 45, 3
+    n = len(names)
+    z = np.stack([np.random.RandomState(sd).randn(1 + 10 * 16) for sd in seeds], axis=1)
+    cho = np.zeros((K * st, n))
+    for h, g in scen:
+        cho[int(round(h * 60))] = g
+    rs = np.random.RandomState(0)
+    acts = rs.uniform(0.0, 0.04, (K, n))
+    for rule, rule_b in ((custom_reward, custom_reward_b), (mean_drop, mean_drop_b)):
+        singles = [T1DSimEnv(T1DPatient.withName(nm), CGMSensor.withName("Dexcom", seed=sd), InsulinPump.withName("Insulet"),
+                             CustomScenario(start_time=t0, scenario=scen)) for nm, sd in zip(names, seeds)]
+        be = BatchedT1DSimEnv(patient=names, sensor="Dexcom", noise="host", normals=z, cgm_history=True)
+        assert be.window == 20
+        for episode in range(2):
+            for s in singles:
+                s.reset()
+            be.reset()
+            w0 = be.cgm_window().cpu().numpy()
+            assert np.isnan(w0[:-1]).all() and np.abs(w0[-1] - [s.CGM_hist[0] for s in singles]).max() < 1e-9
+            for k in range(K if episode == 0 else 8):
+                want = [s.step(Action(basal=acts[k, j], bolus=0), reward_fun=rule) for j, s in enumerate(singles)]
+                obs, rew, done, info = be.step(acts[k], cho=cho[k * st:(k + 1) * st], reward_fun=rule_b)
+                assert np.abs(obs.cpu().numpy() - [w.observation.CGM for w in want]).max() < 1e-9, k
+                assert np.abs(rew.cpu().numpy() - [w.reward for w in want]).max() < 1e-9, (rule.__name__, k)
+                win = be.cgm_window().cpu().numpy()
+                for j, s in enumerate(singles):
+                    h = np.array(s.CGM_hist[-20:])
+                    assert np.abs(win[20 - len(h):, j] - h).max() < 1e-9 and np.isnan(win[:20 - len(h), j]).all()
+        assert be.sync() == 0
+    # the gym-style batch takes the function at construction, as the reference wrapper does
+    genv = BatchedGymT1DSimEnv(256, patient_name="adolescent#002", seed=5, reward_fun=custom_reward_b)
+    o = genv.reset()
+    for _ in range(30):
+        o, r, d, info = genv.step(torch.full((256,), 0.02, dtype=torch.float64, device=o.device))
+        assert torch.equal(r, custom_reward_b(o.unsqueeze(0)))
+    plain = BatchedT1DSimEnv(patient="adult#001", n_envs=4)
+    plain.reset()
+    with pytest.raises(Exception):
+        plain.step(0.01, reward_fun=custom_reward_b)                    # needs cgm_history

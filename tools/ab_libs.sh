@@ -4,7 +4,7 @@
 for spec in "$@"; do
   IFS='|' read -r label lib args <<< "$spec"
   if [ "$lib" = "-" ]; then unset T1D_LIB_PATH; else export T1D_LIB_PATH="$lib"; fi
-  out=$(python bench.py --no-cpu-baseline --steps 600 --warmup 200 $args 2>/dev/null)
+  out=$(python bench.py --no-cpu-baseline --no-accuracy --steps 600 --warmup 200 $args 2>/dev/null)
   python - "$label" "$out" <<'PY'
 import json, sys
 try:
