@@ -211,13 +211,13 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  *       absorbed mass shifted into the state (:151-173,201-202) -- which needs math = 1 and n_sub in {2, 4, 6, 8};
  *   -1 (default) = split whenever those hold, classical RK4 otherwise.
  * "adaptive_gut": step sizes of the split scheme.  1 (default) = per minute and env, by a deterministic rule on the state
- *   and the rates at the start of the minute: level 0 (gut n_sub/2 steps, glucose n_sub/4; calm minutes, ~95 % of the
- *   env-minutes of RandomScenario days; n_sub divisible by 4), level 1 (gut n_sub, glucose n_sub/2), level 2 (gut 4 n_sub,
- *   glucose n_sub: an argument of the gastric-emptying tanh pair, t1dpatient.py:138-140, moves fast through its
- *   transition, a kink of the glucose sub-system -- EGP floor, renal threshold, x3 = 0, :158-167 -- is about to be
- *   crossed, or insulin action makes the tissue compartment fast).  Max error against a tight solve 1.7e-4 mg/dL on
- *   random-meal days (level 1 everywhere: 7e-3).  In one-minute launches the lanes of levels 1 and 2 are set aside and
- *   integrated together at the end of the launch; elsewhere every lane takes its level in place.
+ *   and the rates at the start of the minute: level 1 (gut n_sub steps, glucose n_sub/2) unless an argument of the
+ *   gastric-emptying tanh pair (t1dpatient.py:138-140) moves fast through its transition, x3 is about to reach 0 (:167) or
+ *   insulin action makes the tissue compartment fast (:169-172) -- then level 2 (gut 2 n_sub, glucose n_sub): ~0.7 % of the
+ *   env-minutes of RandomScenario days.  Max error against a tight solve 9e-4 mg/dL on random-meal days (level 1
+ *   everywhere: 7e-3); a glucose state that reaches 0 is held there as the reference holds it.  In one-minute launches the
+ *   lanes of level 2 are set aside and integrated together at the end of the launch; elsewhere a wave runs at the level
+ *   of its most refined lane.
  *   0 = level 1 in every minute; 2 = as 1 but in place in every kernel; 3 = as 1, set aside at any batch size (tests).
  * "math": 1 (default) = exp-based gastric-emptying term and Newton-refined reciprocals in the ODE right-hand side;
  *   0 = ocml tanh and IEEE divisions written exactly as t1dpatient.py:138-140,171,178 writes them, classical RK4
@@ -228,14 +228,14 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * "single_minute_kernel": 1 (default) = one-minute launches on the packed layout take the persistent kernels.
  * "s1_blocks": grid of those kernels (0 = one workgroup per compute unit).
  * "defer_min_chunks", "dreg_max_chunks": thresholds (64-env chunks per workgroup) from which the set-aside form is
- *   used, and below which its deferred passes keep their parameters in vector registers. */
+ *   used, and below which its list pass keeps its parameters in vector registers. */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Host-only helper (no device needed): the tables of the split integrator for one patient row
  * (T1D_P_* order, n_cols == T1D_P_NCOLS) and n_sub in {2, 4, 6, 8}: 28 n_sub + 21 entries of the insulin propagator
  * Phi(k / (2 n_sub)), k = 1 .. 2 n_sub (layout in simglucose_amd/csrc/t1d_device.hpp), followed by the four weights
- * E, wa, wm, wb of the exponential gut update for the gut step of level 1 (h = 1/n_sub), of level 2 (h/4) and of
- * level 0 (2 h); out_len >= 28 n_sub + 33.  What t1d_step uploads; exposed so that the tables can be checked against
+ * E, wa, wm, wb of the exponential gut update for the gut step of level 1 (h = 1/n_sub) and of level 2 (h/2);
+ * out_len >= 28 n_sub + 29.  What t1d_step uploads; exposed so that the tables can be checked against
  * an independent matrix exponential. */
 int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
 

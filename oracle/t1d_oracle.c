@@ -180,12 +180,14 @@ void t1d_o_mr_minute(const double* p, double* x, double cho, double ins, double 
  * Step sizes (integrator 3, "split": level 1 in every minute; integrator 4, "split_adaptive": per minute and env,
  * from the state and the rates at the start of the minute -- o_tier_level below; a deterministic rule, so the HIP
  * kernels take the same decisions):
- *   level 0  gut n_sub/2 steps, glucose n_sub/4   calm minutes: ~95 % of the env-minutes of RandomScenario days
  *   level 1  gut n_sub steps,   glucose n_sub/2   (n_sub = 4: RK4 at h = 1/4 and H = 1/2)
- *   level 2  gut 4 n_sub steps, glucose n_sub     an argument of the gastric-emptying tanh pair (:138-140) moves
- *            fast through its transition, a kink of the glucose sub-system (EGP floor :165, renal threshold
- *            :158-161, x3 = 0 :167) is about to be crossed, or the tissue compartment is fast (large insulin action)
- * Against a tight solve on 600 random env-days: max 1.7e-4 mg/dL (level 1 everywhere: 6.9e-3) -- tools/tier_study.py.
+ *   level 2  gut 2 n_sub steps, glucose n_sub     an argument of the gastric-emptying tanh pair (:138-140) moves fast
+ *            through its transition, x3 is about to reach 0 (:167), or insulin action makes the tissue compartment
+ *            fast (:169-172): ~0.7 % of the env-minutes of RandomScenario days
+ * Against a tight solve on random env-days: max 9.2e-4 mg/dL (level 1 everywhere: 6.9e-3); patients driven through
+ * BG = 0 stay within 7e-4 of the SciPy solution -- tools/tier_study.py.  (A third, coarser level for calm minutes and a
+ * finer level 2 were built and measured in round 2: 1.7e-4, but every kernel that takes its levels in place pays for
+ * the most expensive lane of each wave, and the one-minute kernel is bound by HBM, not arithmetic -- DESIGN.md.)
  * ---------------------------------------------------------------------------------------- */
 static double o_kgut(const double* p, double qsto, double Dbar)
 {
@@ -215,25 +217,22 @@ static void o_glucose_rhs(const double* p, const double* y, double cR, double cR
     dy[0] = d3; dy[1] = d4; dy[2] = d12;
 }
 
-/* Knobs of the step-size rule (study builds / tools may override them through t1d_o_set_knob; the defaults are what
- * the HIP kernels hard-code):
+/* Knobs of the step-size rule (tools may override them through t1d_o_set_knob for studies; the defaults are what the
+ * HIP kernels hard-code):
  *   0 NEAR   |tanh argument| below this somewhere in the minute ...
- *   1 MOVE   ... while it changes by more than this over the minute       -> level 2 (gut)
- *   2 CALM   both tanh arguments change by less than this over the minute  -> level 0 allowed (gut)
- *   3 KINK2  a kink function g (EGP, x3 - ke2, x3) with min(|g0|, |g1|) < KINK2 |g1 - g0| or a sign change -> level 2
- *   4 KINK0  min(|g0|, |g1|) < KINK0 |g1 - g0| (or a sign change)         -> level 0 not allowed
- *   5 SNAP   x3 that a glucose step takes from >= 0 to < 0 is set to -SNAP (0 = leave it)
- *   6 STIFF0 rate of the tissue compartment Vmt / (Km0 + x4) + k2 above this (1/min) -> level 0 not allowed
- *   7 STIFF2 ... above this                                               -> level 2                              */
-static double o_knob[8] = {3.0, 4.0, 1.0, 1.0, 2.0, 1e-10, 0.4, 1.0};
-void t1d_o_set_knob(int k, double v) { if (k >= 0 && k < 8) o_knob[k] = v; }
-double t1d_o_get_knob(int k) { return (k >= 0 && k < 8) ? o_knob[k] : 0.0; }
+ *   1 MOVE   ... while it changes by more than this over the minute                      -> level 2 (gut)
+ *   2 KINK   x3 >= 0 with min(|x3|, |x3 + dx3|) < KINK |dx3|, or x3 + dx3 < 0              -> level 2 (x3 reaches 0, :167)
+ *   3 SNAP   x3 that a glucose step takes from >= 0 to < 0 is set to -SNAP (0 = leave it)
+ *   4 STIFF  rate of the tissue compartment Vmt / (Km0 + x4) + k2 above this (1/min)      -> level 2               */
+static double o_knob[5] = {3.0, 4.0, 1.0, 1e-10, 2.0};
+void t1d_o_set_knob(int k, double v) { if (k >= 0 && k < 5) o_knob[k] = v; }
+double t1d_o_get_knob(int k) { return (k >= 0 && k < 5) ? o_knob[k] : 0.0; }
 
-/* The step-size rule: level of the minute from the state and the rates at its start.  dq = d(qsto)/dt,
- * k0[3] = glucose RHS (dz3, dx4, dx12) there, xl_dot = d(x8)/dt there. */
-static int o_tier_level(const double* p, const double* x, double Dbar, double dq, const double* k0, double xl_dot)
+/* The step-size rule: level of the minute from the state and the rates at its start.  dq = d(qsto)/dt, dx3 = dx3/dt
+ * (rate of appearance included). */
+static int o_tier_level(const double* p, const double* x, double Dbar, double dq, double dx3)
 {
-    int lvl2 = 0, calm = 1;
+    int lvl2 = 0;
     if (Dbar > 0.0) {
         const double aa = 5.0 / 2.0 / (1.0 - p[T1D_O_B]) / Dbar, cc = 5.0 / 2.0 / p[T1D_O_D] / Dbar;
         const double q0 = x[0] + x[1];
@@ -242,29 +241,21 @@ static int o_tier_level(const double* p, const double* x, double Dbar, double dq
         const int fa = fabs(A1 - A0) > o_knob[1] && (A0 * A1 <= 0.0 || fmin(fabs(A0), fabs(A1)) < o_knob[0]);
         const int fc = fabs(C1 - C0) > o_knob[1] && (C0 * C1 <= 0.0 || fmin(fabs(C0), fabs(C1)) < o_knob[0]);
         lvl2 = fa || fc;
-        calm = fabs(A1 - A0) < o_knob[2] && fabs(C1 - C0) < o_knob[2];
     }
-    /* kinks of the glucose sub-system (t1dpatient.py:158-167): g and its rate at the start of the minute */
-    const double x3 = x[3], d3 = k0[0];                                  /* k0[0] = dx3/dt incl. the rate of appearance */
-    const double g[3] = {p[T1D_O_KP1] - p[T1D_O_KP2] * x3 - p[T1D_O_KP3] * x[8], x3 - p[T1D_O_KE2], x3};
-    const double dg[3] = {-p[T1D_O_KP2] * d3 - p[T1D_O_KP3] * xl_dot, d3, d3};
-    for (int j = 0; j < 3; ++j) {
-        const double g1 = g[j] + dg[j], m = fmin(fabs(g[j]), fabs(g1)), ad = fabs(dg[j]);
-        if (j == 2 && g[j] < 0.0) { calm = 0; continue; }                /* x3 < 0: held (:167), no kink ahead; never level 0 */
-        if (g[j] * g1 <= 0.0 || m < o_knob[3] * ad) lvl2 = 1;
-        if (g[j] * g1 <= 0.0 || m < o_knob[4] * ad) calm = 0;
+    const double x3 = x[3];
+    if (x3 >= 0.0) {                                                     /* (x3 < 0 is held: nothing ahead) */
+        const double x3e = x3 + dx3;
+        if (x3e <= 0.0 || fmin(x3, x3e) < o_knob[2] * fabs(dx3)) lvl2 = 1;
     }
     /* insulin-dependent utilisation (:169-172) makes the tissue compartment fast under large insulin action */
     const double lam4 = (p[T1D_O_VM0] + p[T1D_O_VMX] * x[6]) / (p[T1D_O_KM0] + x[4]) + p[T1D_O_K2];
-    if (lam4 > o_knob[6]) calm = 0;
-    if (lam4 > o_knob[7]) lvl2 = 1;
-    return lvl2 ? 2 : (calm ? 0 : 1);
+    if (lam4 > o_knob[4]) lvl2 = 1;
+    return lvl2 ? 2 : 1;
 }
 
-/* tab: [2 n_sub][7][9] Phi(k / (2 n_sub)), k = 1 .. 2 n_sub, then (E, wa, wm, wb) for h = 2/n_sub, 1/n_sub, 1/(4 n_sub).
- * mode 0: level 1 in every minute (gut n_sub steps, glucose n_sub/2: the fixed-step "split" scheme);
- * mode 1: level by o_tier_level -- 0: gut n_sub/2 steps, glucose n_sub/4 (n_sub divisible by 4, else level 1);
- *         1: as mode 0; 2: gut 4 n_sub steps (two per glucose half step), glucose n_sub.
+/* tab: [2 n_sub][7][9] Phi(k / (2 n_sub)), k = 1 .. 2 n_sub, then (E, wa, wm, wb) for the gut step of level 1
+ * (h = 1/n_sub) and of level 2 (h/2).
+ * mode 0: level 1 in every minute (the fixed-step "split" scheme); mode 1: level by o_tier_level.
  * Returns the level used, or -1 on bad arguments. */
 int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho, double ins, double lq,
                        double lf, int n_sub, int mode)
@@ -279,17 +270,14 @@ int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho
     if (mode == 1) {
         const double F1 = o_kgut(p, x[0] + x[1], Dbar) * x[1];
         double k0[3];
-        o_glucose_rhs(p, y, 0.0, 0.0, x[6], x[8], 0.0, k0);                /* dz3 without the Rat term ... */
-        k0[0] += (x[3] >= 0.0) ? c * kabs * x[2] : 0.0;                 /* ... so dx3 = dz3 + c kabs x2 (:151,165) */
-        level = o_tier_level(p, x, Dbar, d - F1, k0, -p[T1D_O_KI] * (x[8] - x[7]));
-        if (level == 0 && (n_sub & 3)) level = 1;
+        o_glucose_rhs(p, y, 0.0, 0.0, x[6], x[8], 0.0, k0);           /* dz3 without the Rat term ... */
+        const double dx3 = k0[0] + ((x[3] >= 0.0) ? c * kabs * x[2] : 0.0);   /* ... so dx3 = dz3 + c kabs x2 (:151,165) */
+        level = o_tier_level(p, x, Dbar, d - F1, dx3);
     }
-    const int gm = level == 2 ? 2 : 1;                                              /* gut steps per glucose half step */
-    const int nh = level == 0 ? n_sub / 2 : (level == 1 ? n_sub : 2 * n_sub);      /* glucose half steps */
-    const int ng = nh * gm;                                                         /* gut steps */
-    const int ns = nh / 2;                                                          /* glucose steps */
-    const int sb = nb / nh;                                                         /* table blocks per glucose half step */
-    /* insulin: exact propagation to every tau = k/ng */
+    const int nh = level == 1 ? n_sub : 2 * n_sub;                        /* gut steps = glucose half steps */
+    const int ns = nh / 2;                                                /* glucose steps */
+    const int sb = nb / nh;                                               /* table blocks per half step */
+    /* insulin: exact propagation to every tau = k/nh */
     double aug[9], S[17][7];
     for (int j = 0; j < 7; ++j) { aug[j] = x[SI[j]]; S[0][j] = aug[j]; }
     aug[7] = u; aug[8] = 1.0;
@@ -299,13 +287,13 @@ int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho
             for (int j = 0; j < 9; ++j) a += tab[((k * sb - 1) * 7 + i) * 9 + j] * aug[j];
             S[k][i] = a;
         }
-    const double* wt = tab + nb * 63 + 4 * level;
+    const double* wt = tab + nb * 63 + 4 * (level - 1);
     const double E = wt[0], wa = wt[1], wm = wt[2], wb = wt[3];
     /* gut */
-    const double h = 1.0 / (double)ng;
-    double g0 = x[0], g1 = x[1], x2 = x[2], Q = 0.0, R[33], X2[33];
+    const double h = 1.0 / (double)nh;
+    double g0 = x[0], g1 = x[1], x2 = x[2], Q = 0.0, R[17], X2[17];
     R[0] = 0.0; X2[0] = x2;
-    for (int s = 0; s < ng; ++s) {
+    for (int s = 0; s < nh; ++s) {
         double a0, a1, F1, F2, F3, F4, b0, b1, c0, c1, e0, e1, y0, y1;
         F1 = o_kgut(p, g0 + g1, Dbar) * g1; a0 = -kmax * g0 + d; a1 = kmax * g0 - F1;
         y0 = g0 + 0.5 * h * a0; y1 = g1 + 0.5 * h * a1;
@@ -318,7 +306,7 @@ int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho
         g1 += h / 6.0 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
         Q += h / 6.0 * (F1 + 2.0 * F2 + 2.0 * F3 + F4);
         x2 = E * x2 + wa * F1 + wm * (0.5 * (F2 + F3)) + wb * F4;
-        if ((s + 1) % gm == 0) { X2[(s + 1) / gm] = x2; R[(s + 1) / gm] = x[2] - x2 + Q; }
+        X2[s + 1] = x2; R[s + 1] = x[2] - x2 + Q;
     }
     /* glucose: x3 itself is carried from step to step (z3 = x3 - c R is formed per step), so that a held x3 stays
      * bit for bit what it was in any precision */
@@ -338,7 +326,7 @@ int t1d_o_split_minute(const double* p, const double* tab, double* x, double cho
         for (int i = 0; i < 3; ++i) y[i] += H / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
         double x3b = y[0] + c * R[ib];
         if (fz < 0.0) x3b = x3a;                                        /* held */
-        else if (o_knob[5] > 0.0 && x3b < 0.0) x3b = -o_knob[5];        /* crossed zero in this step */
+        else if (o_knob[3] > 0.0 && x3b < 0.0) x3b = -o_knob[3];        /* crossed zero in this step */
         x3a = x3b;
     }
     x[0] = g0; x[1] = g1; x[2] = x2;

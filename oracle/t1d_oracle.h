@@ -48,8 +48,8 @@ typedef struct {
     int32_t* n_draws;          /* [n] normals consumed */
     double* prev_cgm;          /* [n] CGM_hist[-1] before this step (default reward) */
     const double* split_tab;   /* [n_patients][split_stride] tables of the split scheme (integrators 3, 4) or NULL */
-    int32_t split_stride;      /* = 126 n_sub + 12 */
-    int64_t* level_count;      /* [3] or NULL: env-minutes integrated at level 0 / 1 / 2 of the split scheme (studies) */
+    int32_t split_stride;      /* = 126 n_sub + 8 */
+    int64_t* level_count;      /* [3] or NULL: env-minutes integrated at level 1 / 2 of the split scheme ([0] unused; studies) */
 } t1d_o_batch;
 
 typedef struct {

@@ -172,13 +172,13 @@ def split_tables(ptab, n_sub):
     """Host tables of the split scheme (t1d_oracle.c, integrators 3 and 4) for every row of `ptab`:
     [2 n_sub][7][9] exact propagators Phi(k / (2 n_sub)) of the linear insulin sub-system
     s = (x5, x9, x10, x11, x6, x7, x8) augmented with (u, 1)  (t1dpatient.py:176-198), from
-    scipy.linalg.expm, then the ETD-RK4 weights (E, wa, wm, wb) of x2' = -kabs x2 + F for the gut steps of the
-    three levels, h = 2/n_sub, 1/n_sub, 1/(4 n_sub), by Gauss-Legendre quadrature of the quadratic interpolant
-    against exp(-kabs (h-s))."""
+    scipy.linalg.expm, then the ETD-RK4 weights (E, wa, wm, wb) of x2' = -kabs x2 + F for the gut steps of level 1
+    (h = 1/n_sub) and of level 2 (h/2), by Gauss-Legendre quadrature of the quadratic interpolant against
+    exp(-kabs (h-s))."""
     from scipy.linalg import expm
     ptab = np.atleast_2d(ptab)
     nb = 2 * n_sub
-    out = np.zeros((ptab.shape[0], nb * 63 + 12))
+    out = np.zeros((ptab.shape[0], nb * 63 + 8))
     gx, gw = np.polynomial.legendre.leggauss(32)
     for r, p in enumerate(ptab):
         g = lambda k: p[IDX[k]]
@@ -192,7 +192,7 @@ def split_tables(ptab, n_sub):
         A[6, 6] = -g("ki"); A[6, 5] = g("ki")                                                         # x8  :187
         for k in range(1, nb + 1):
             out[r, (k - 1) * 63:k * 63] = expm(A * (k / nb))[:7].ravel()
-        for part, hh in enumerate((2.0 / n_sub, 1.0 / n_sub, 0.25 / n_sub)):     # gut step of level 0, 1, 2
+        for part, hh in enumerate((1.0 / n_sub, 0.5 / n_sub)):                     # gut step of level 1, 2
             ss = (gx + 1.0) * hh / 2.0; ww = gw * hh / 2.0
             Lah = (ss - hh / 2) * (ss - hh) / ((0 - hh / 2) * (0 - hh))
             Lmh = (ss - 0) * (ss - hh) / ((hh / 2) * (hh / 2 - hh))

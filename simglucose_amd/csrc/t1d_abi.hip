@@ -39,7 +39,7 @@ struct t1d_ctx {
     int np_pad = 0;
     double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
-    int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of levels 1, 2 aside from this many chunks per CU up
+    int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of level 2 aside from this many chunks per CU up
     int dreg_max_chunks = 65535;     // ... and run the list passes with VGPR parameters below this many chunks per CU
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
@@ -121,7 +121,7 @@ static void mat_expm(int n, const double* A, double* E)
 }
 
 // One patient row -> kPropRows(n_sub) propagator entries (layout: t1d_device.hpp) followed by the four x2 weights
-// E, wa, wm, wb for the gut step of level 1 (h = 1/n_sub), of level 2 (h/4) and of level 0 (2 h).  The insulin
+// E, wa, wm, wb for the gut step of level 1 (h = 1/n_sub) and of level 2 (h/2).  The insulin
 // sub-system in the order s = (x5, x9, x10, x11, x6, x7, x8, u, 1) (t1dpatient.py:176-198); weights of
 // x2' = -kabs x2 + F (:148) from the moments I_k = int_0^1 exp(-z (1 - s)) s^k ds = sum_j (-z)^j k! / (k + j + 1)!,
 // z = kabs h, of the quadratic through F(0), F(h/2), F(h).
@@ -164,8 +164,8 @@ static void split_tables_row(const double* r, int n_sub, double* out)
     static const int c7[6] = {5, 0, 1, 2, 3, 7};
     for (int j = 0; j < 6; ++j) t[15 + j] = Pk[5 * 9 + c7[j]];
     const double h1 = 1.0 / (double)n_sub;
-    const double hs[3] = {h1, 0.25 * h1, 2.0 * h1};      // gut step of level 1, 2, 0 (the order of DP_X2E, DP_X2E2, DP_X2E0)
-    for (int part = 0; part < 3; ++part) {
+    const double hs[2] = {h1, 0.5 * h1};                 // gut step of level 1, 2 (the order of DP_X2E, DP_X2E2)
+    for (int part = 0; part < 2; ++part) {
         const double hh = hs[part], z = r[T1D_P_KABS] * hh;
         double I[3];
         for (int k = 0; k < 3; ++k) {
@@ -192,7 +192,7 @@ extern "C" int t1d_split_tables(const double* patient_row, int n_cols, int n_sub
     if (!patient_row || !out) return fail(T1D_E_INVALID, "t1d_split_tables: NULL argument");
     if (n_cols != T1D_P_NCOLS) return fail(T1D_E_INVALID, "t1d_split_tables: n_cols must be T1D_P_NCOLS (45)");
     if (n_sub < 2 || n_sub > 8 || (n_sub & 1)) return fail(T1D_E_INVALID, "t1d_split_tables: n_sub must be 2, 4, 6 or 8");
-    if (out_len < kPropRows(n_sub) + 12) return fail(T1D_E_INVALID, "t1d_split_tables: out_len < 28 n_sub + 33");
+    if (out_len < kPropRows(n_sub) + 8) return fail(T1D_E_INVALID, "t1d_split_tables: out_len < 28 n_sub + 29");
     split_tables_row(patient_row, n_sub, out);
     return T1D_OK;
 }
@@ -200,15 +200,15 @@ extern "C" int t1d_split_tables(const double* patient_row, int n_cols, int n_sub
 // (re)build the device tables of the split integrator for n_sub sub-steps per minute
 static int ensure_split(t1d_ctx* c, int ng)
 {
-    static_assert(DP_X2WB0 == DP_X2E + 11 && DP_X2E2 == DP_X2E + 4 && DP_X2E0 == DP_X2E + 8, "x2 weight rows are consecutive");
+    static_assert(DP_X2WB2 == DP_X2E + 7 && DP_X2E2 == DP_X2E + 4, "x2 weight rows are consecutive");
     if (c->split_nsub == ng) return T1D_OK;
     T1D_HIP(hipDeviceSynchronize());                     // kernels in flight may still be reading the old tables
     const int rows = kPropRows(ng), npp = c->np_pad;
-    std::vector<double> prop((size_t)rows * npp, 0.0), one((size_t)rows + 12);
+    std::vector<double> prop((size_t)rows * npp, 0.0), one((size_t)rows + 8);
     for (int j = 0; j < c->np; ++j) {
         split_tables_row(c->ptab.data() + (size_t)j * T1D_P_NCOLS, ng, one.data());
         for (int k = 0; k < rows; ++k) prop[(size_t)k * npp + j] = one[k];
-        for (int k = 0; k < 12; ++k) c->dpar[(size_t)(DP_X2E + k) * kMaxPatients + j] = one[rows + k];   // DP_X2E .. DP_X2WB0
+        for (int k = 0; k < 8; ++k) c->dpar[(size_t)(DP_X2E + k) * kMaxPatients + j] = one[rows + k];   // DP_X2E .. DP_X2WB2
     }
     std::vector<float> propf(prop.begin(), prop.end()), dpf(c->dpar.begin(), c->dpar.end());
     (void)hipFree(c->d_prop64); (void)hipFree(c->d_prop32); c->d_prop64 = nullptr; c->d_prop32 = nullptr;
@@ -496,13 +496,13 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             if (blocks > nchunks) blocks = nchunks;
             const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
             const bool tiered = c->adaptive_gut != 0;
-            // per-minute step sizes: lanes of levels 1 and 2 set aside and integrated together at the end of the launch
-            // (step1d_kernel) at n_sub = 4 (its unrolled integration) where the two lists of the CU's envs fit next to
-            // the tables; adaptive_gut = 2 asks for the in-place form, 3 for the deferred form at any batch size
+            // per-minute step sizes: lanes of level 2 set aside and integrated together at the end of the launch
+            // (step1d_kernel) where the list of the CU's envs fits next to the tables; adaptive_gut = 2 asks for the
+            // in-place form, 3 for the set-aside form at any batch size
             const int per_block = (nchunks + blocks - 1) / blocks;
-            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * 2 * sizeof(uint16_t);
+            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(uint16_t);
             const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
-                               stride == 32 && n_sub == 4 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
+                               stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
         hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
 #define T1D_LAUNCH_S1D(TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR>, dyn1d)); \

@@ -31,12 +31,12 @@ enum DevPar : int {
     DP_IB, DP_KI, DP_M130 /*m1+m30*/, DP_M2, DP_KA1KD /*ka1+kd*/, DP_KD, DP_KSC, DP_INSC /*6000/BW*/,
     DP_VG, DP_IVI /*1/Vi*/, DP_IVG /*1/Vg*/, DP_DK /*kmax-kmin*/,
     // split integrator only; the x2 weights depend on n_sub and are rewritten when it changes: gut step of level 1
-    // (h = 1/n_sub), of level 2 (h/4) and of level 0 (2 h)
+    // (h = 1/n_sub) and of level 2 (h/2)
     DP_CF /*f/BW*/, DP_X2E /*exp(-kabs h)*/, DP_X2WA, DP_X2WM, DP_X2WB,
-    DP_X2E2, DP_X2WA2, DP_X2WM2, DP_X2WB2, DP_X2E0, DP_X2WA0, DP_X2WM0, DP_X2WB0, DP_COUNT
+    DP_X2E2, DP_X2WA2, DP_X2WM2, DP_X2WB2, DP_COUNT
 };
 constexpr int DP_RK4_COUNT = DP_CF;    // rows the classical-RK4 kernels stage
-constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 51 x 64 x 8 B = 25.5 KiB
+constexpr int kMaxPatients = 64;       // row stride of the table (device and LDS): 47 x 64 x 8 B = 23.5 KiB
 constexpr int kBlock = 256;
 
 // parameters re-read from LDS at every use; refresh() makes the base opaque so the compiler
@@ -58,7 +58,7 @@ __device__ constexpr int kRhsPars[] = {DP_KMAX, DP_DK, DP_KABS, DP_RATC, DP_KP1,
 // the parameters the split integrator reads inside its loops (the x2 weights by level: kSplitW below)
 __device__ constexpr int kSplitPars[] = {DP_KMAX, DP_DK, DP_RATC, DP_KP1, DP_KP2, DP_KP3, DP_FSNC, DP_KE1, DP_KE2, DP_K1, DP_K2,
                                          DP_VM0, DP_VMX, DP_KM0, DP_KSC, DP_CF};
-__host__ __device__ constexpr int kSplitW(int level) { return level == 0 ? DP_X2E0 : (level == 1 ? DP_X2E : DP_X2E2); }
+__host__ __device__ constexpr int kSplitW(int level) { return level == 1 ? DP_X2E : DP_X2E2; }
 // parameters gathered once per lane from the (L2-resident) table and held in VGPRs for the launch
 template <typename T> struct ParsReg {
     static constexpr bool kSplitRk4 = true;    // measured: 75 us/minute split vs 79 unsplit, and far fewer spills around the loop
@@ -394,13 +394,12 @@ __device__ __forceinline__ void rk4_substeps_split(P& p, const MinuteIn<T>& u, T
 //            from the propagator.  A step that begins with x3 < 0 holds x3 (every stage of the reference's RHS
 //            returns dx3 = 0 there, :167); a step that takes x3 below zero ends at -1e-10, which is where scipy's
 //            step-size control leaves it (a fixed step would overshoot by up to ~0.1 mg/kg and keep that).
-// Step sizes per minute and env -- LEVEL -- from the state and the rates at the start of the minute (tier_level):
-//   0  gut n_sub/2 steps, glucose n_sub/4     calm minutes, ~95 % of the env-minutes of RandomScenario days
+// Step sizes per minute and env -- the level -- from the state and the rates at the start of the minute (tier_level):
 //   1  gut n_sub steps,   glucose n_sub/2     (the fixed-step form of the scheme takes this one in every minute)
-//   2  gut 4 n_sub steps, glucose n_sub       an argument of the gastric-emptying tanh pair (:138-140) moves fast
-//      through its transition, a kink of the glucose sub-system (EGP floor :165, renal threshold :158-161,
-//      x3 = 0 :167) is about to be crossed, or the tissue compartment is fast (large insulin action)
-// Against a tight solve of 600 random env-days: max 1.7e-4 mg/dL (level 1 everywhere: 6.9e-3).
+//   2  gut 2 n_sub steps, glucose n_sub       an argument of the gastric-emptying tanh pair (:138-140) moves fast through
+//      its transition, x3 is about to reach 0 (:167), or insulin action makes the tissue compartment fast (:169-172):
+//      ~0.7 % of the env-minutes of RandomScenario days
+// Against a tight solve of random env-days: max 9.2e-4 mg/dL (level 1 everywhere: 6.9e-3).
 //
 // Propagator rows, 2 n_sub blocks of 14 then a tail of 21 (kPropRows(n_sub) = 28 n_sub + 21):
 //   block k = 1..2 n_sub at (k-1)*14, tau = k/(2 n_sub):
@@ -469,12 +468,12 @@ __device__ __forceinline__ void glucose_rhs(P& p, T y3, T y4, T y12, T cR, T cD,
     if (q4) *q4 = q;
 }
 
-// The step-size rule (oracle: o_tier_level, same constants).  F1 = kgut_flux at the start of the minute, dx3 = dx3/dt
-// there (rate of appearance included), q4 = Vmt / (Km0 + x4) there.  Per lane, deterministic.
+// The step-size rule (oracle: o_tier_level, same constants) -> level 2?  F1 = kgut_flux at the start of the minute,
+// dx3 = dx3/dt there (rate of appearance included), q4 = Vmt / (Km0 + x4) there.  Per lane, deterministic.
 template <typename T, typename P>
-__device__ __forceinline__ int tier_level(P& p, const MinuteIn<T>& u, const T (&x)[13], T F1, T dx3, T q4)
+__device__ __forceinline__ bool tier_level2(P& p, const MinuteIn<T>& u, const T (&x)[13], T F1, T dx3, T q4)
 {
-    const T kNear = T(3), kMove = T(4), kCalm = T(1), kKink2 = T(1), kKink0 = T(2), kStiff0 = T(0.4), kStiff2 = T(1);
+    const T kNear = T(3), kMove = T(4), kKink = T(1), kStiff = T(2);
     // gut: the arguments of the tanh pair and how far they move in this minute by the rate at its start
     const T dq = u.d_mg - F1;                                   // d(qsto)/dt
     const T q0 = x[0] + x[1];
@@ -483,39 +482,31 @@ __device__ __forceinline__ int tier_level(P& p, const MinuteIn<T>& u, const T (&
     const T A1 = A0 + dA, C1 = C0 + dC;
     bool l2 = (fabs(dA) > kMove && (A0 * A1 <= T(0) || t_min(fabs(A0), fabs(A1)) < kNear)) ||
               (fabs(dC) > kMove && (C0 * C1 <= T(0) || t_min(fabs(C0), fabs(C1)) < kNear));
-    bool calm = fabs(dA) < kCalm && fabs(dC) < kCalm;
-    // kinks of the glucose sub-system: g and where the rate at the start of the minute takes it
-    const T x3 = x[3];
-    const T xl_dot = -p(DP_KI) * (x[8] - x[7]);                                                 // :187
-    auto kink = [&](T g, T dg) {
-        const T g1 = g + dg, m = t_min(fabs(g), fabs(g1)), ad = fabs(dg);
-        const bool cross = g * g1 <= T(0);
-        l2 = l2 || cross || m < kKink2 * ad;
-        calm = calm && !(cross || m < kKink0 * ad);
-    };
-    kink(p(DP_KP1) - p(DP_KP2) * x3 - p(DP_KP3) * x[8], -p(DP_KP2) * dx3 - p(DP_KP3) * xl_dot);    // EGP floor, :153,165
-    kink(x3 - p(DP_KE2), dx3);                                                                   // renal threshold, :158
-    if (x3 >= T(0)) kink(x3, dx3); else calm = false;                                            // x3 = 0, :167; a held x3 is never level 0
-    const T lam4 = q4 + p(DP_K2);                               // rate of the tissue compartment under the current insulin action
-    calm = calm && !(lam4 > kStiff0);
-    l2 = l2 || lam4 > kStiff2;
-    return l2 ? 2 : (calm ? 0 : 1);
+    // x3 about to reach 0 (:167; a held x3 < 0 has nothing ahead)
+    const T x3 = x[3], x3e = x3 + dx3;
+    l2 = l2 || (x3 >= T(0) && (x3e <= T(0) || t_min(x3, x3e) < kKink * fabs(dx3)));
+    // rate of the tissue compartment under the current insulin action (:169-172)
+    return l2 || q4 + p(DP_K2) > kStiff;
 }
 
-// One minute at a given LEVEL.  HAVE_F1: the caller has evaluated kgut_flux at the start of the minute already (for the
-// step-size rule) and hands it in.  (Keeping the rule's first glucose stage as well costs three register pairs across
-// the gut steps: spills, measured slower.)
+// One minute.  LEVEL 1 / 2: every lane at that level (compile-time step sizes and table rows); LEVEL 0: every lane at its
+// own level, `refine` = level 2 -- one loop whose trip count, step sizes, x2 weights and table rows are per-lane values,
+// so a wave runs as long as its most refined lane and the others sit out the extra rounds (kernels that keep the state in
+// registers across minutes; the single-minute kernel sets level-2 lanes aside instead).
+// HAVE_F1: the caller has evaluated kgut_flux at the start of the minute already (for the step-size rule) and hands it
+// in.  (Keeping the rule's first glucose stage as well costs three register pairs across the gut steps: spills.)
 template <int LEVEL, typename T, typename P, typename PR, bool HAVE_F1 = false>
-__device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0))
+__device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0),
+                                            bool refine = false)
 {
-    constexpr int GM = LEVEL == 2 ? 2 : 1;                      // gut steps per glucose half step
-    constexpr int SB = LEVEL == 0 ? 4 : (LEVEL == 1 ? 2 : 1);   // propagator blocks per glucose half step
-    constexpr int W = kSplitW(LEVEL);
-    const int nh = (2 * n_sub) / SB;                            // glucose half steps in the minute
+    const bool r2 = LEVEL == 2 || (LEVEL == 0 && refine);        // this lane at level 2
+    const int sb = r2 ? 1 : 2;                                    // propagator blocks per glucose half step
+    const int nh = r2 ? 2 * n_sub : n_sub;                        // glucose half steps = gut steps in the minute
     const int ns = nh >> 1;
-    const T h = T(1) / T(nh);                                   // glucose half step
-    const T H = h + h, H6 = H / T(6);
-    const T gh = GM == 2 ? T(0.5) * h : h, ghh = T(0.5) * gh, gh6 = gh / T(6);      // gut step
+    const T h = T(1) / T(nh);                                     // glucose half step = gut step
+    const T H = h + h, H6 = H / T(6), hh = T(0.5) * h, h6 = h / T(6);
+    const T wE = r2 ? p(DP_X2E2) : p(DP_X2E), wA = r2 ? p(DP_X2WA2) : p(DP_X2WA);
+    const T wM = r2 ? p(DP_X2WM2) : p(DP_X2WM), wB = r2 ? p(DP_X2WB2) : p(DP_X2WB);
     const T s5 = x[5], s6 = x[6], s7 = x[7], s8 = x[8], s9 = x[9], s10 = x[10], s11 = x[11], ui = u.ins;
     T g0 = x[0], g1 = x[1], x2 = x[2], R = T(0);      // R: mass that left x2 through kabs since the minute began
     T x3a = x[3], x4 = x[4], x12 = x[12];             // x3 itself is carried from step to step: a held value stays bit for bit
@@ -532,26 +523,26 @@ __device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T
         if (HAVE_F1 && have_f1) F1 = f1_pre; else F1 = kgutF(g0, g1);
         post(0, F1);
         const T a0 = u.d_mg - kmax * g0, a1 = kmax * g0 - F1;
-        T y0 = g0 + ghh * a0, y1 = g1 + ghh * a1;
+        T y0 = g0 + hh * a0, y1 = g1 + hh * a1;
         pre(1);
         const T F2 = kgutF(y0, y1);
         post(1, F2);
         const T b0 = u.d_mg - kmax * y0, b1 = kmax * y0 - F2;
-        y0 = g0 + ghh * b0; y1 = g1 + ghh * b1;
+        y0 = g0 + hh * b0; y1 = g1 + hh * b1;
         pre(2);
         const T F3 = kgutF(y0, y1);
         post(2, F3);
         const T c0 = u.d_mg - kmax * y0, c1 = kmax * y0 - F3;
-        y0 = g0 + gh * c0; y1 = g1 + gh * c1;
+        y0 = g0 + h * c0; y1 = g1 + h * c1;
         pre(3);
         const T F4 = kgutF(y0, y1);
         post(3, F4);
         const T e0 = u.d_mg - kmax * y0, e1 = kmax * y0 - F4;
         const T F23 = F2 + F3;
-        g0 += gh6 * (a0 + T(2) * (b0 + c0) + e0);
-        g1 += gh6 * (a1 + T(2) * (b1 + c1) + e1);
-        const T x2n = p(W) * x2 + p(W + 1) * F1 + p(W + 2) * (T(0.5) * F23) + p(W + 3) * F4;
-        R += (x2 - x2n) + gh6 * (F1 + T(2) * F23 + F4);     // d(x2 + R) = kgut x1 dt
+        g0 += h6 * (a0 + T(2) * (b0 + c0) + e0);
+        g1 += h6 * (a1 + T(2) * (b1 + c1) + e1);
+        const T x2n = wE * x2 + wA * F1 + wM * (T(0.5) * F23) + wB * F4;
+        R += (x2 - x2n) + h6 * (F1 + T(2) * F23 + F4);     // d(x2 + R) = kgut x1 dt
         x2 = x2n;
     };
     auto no_pre = [](int) {};
@@ -560,7 +551,7 @@ __device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T
     for (int s = 0; s < ns; ++s) {
         // the four propagator rows of this glucose step (x6, x8 at its middle and at its end) ride along the four
         // stages of its first gut step: one row at a time (28 table reads in flight at once would cost 56 VGPRs)
-        const int rm = ((2 * s + 1) * SB - 1) * 14, re = rm + SB * 14;
+        const int rm = ((2 * s + 1) * sb - 1) * 14, re = rm + sb * 14;
         T cf[7], x6m, x8m, x6b, x8b;
         auto pre = [&](int k) {
             const int r = (k < 2 ? rm : re) + 7 * (k & 1);
@@ -576,12 +567,10 @@ __device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T
             if (k == 0) x6m = v6; else if (k == 1) x8m = v8; else if (k == 2) x6b = v6; else x8b = v8;
         };
         gut_step(pre, post, s == 0);
-        if (GM == 2) gut_step(no_pre, no_post, false);
         const T cRm = p(DP_CF) * R, cDm = p(DP_RATC) * x2;
         gut_step(no_pre, no_post, false);
-        if (GM == 2) gut_step(no_pre, no_post, false);
         const T cRb = p(DP_CF) * R, cDb = p(DP_RATC) * x2;
-        const bool hold = LEVEL != 0 && x3a < T(0);          // (level 0 is never chosen with x3 < 0)
+        const bool hold = x3a < T(0);
         T z3 = x3a - cRa;
         T k3, k4, k12, a3, a4, a12;
         glucose_rhs(p, z3, x4, x12, cRa, cDa, x6a, x8a, hold, x3a, k3, k4, k12);
@@ -608,29 +597,25 @@ __device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T
 }
 
 // what the step-size rule needs at the start of the minute; F1 is reused by the integration
-template <typename T> struct TierPre { T f1, k3, k4, k12; int level; };
+template <typename T> struct TierPre { T f1; bool level2; };
 template <typename T, typename P>
-__device__ __forceinline__ TierPre<T> tier_pre(P& p, const MinuteIn<T>& u, const T (&x)[13], int n_sub)
+__device__ __forceinline__ TierPre<T> tier_pre(P& p, const MinuteIn<T>& u, const T (&x)[13])
 {
     TierPre<T> t;
     t.f1 = kgut_flux(p, u, x[0], x[1]);
     const T cD = p(DP_RATC) * x[2];
-    T q4;
-    glucose_rhs(p, x[3], x[4], x[12], T(0), cD, x[6], x[8], x[3] < T(0), x[3], t.k3, t.k4, t.k12, &q4);
-    t.level = tier_level(p, u, x, t.f1, t.k3 + cD, q4);          // dx3 = dz3 + c R' (0 while x3 < 0)
-    if (t.level == 0 && (n_sub & 3)) t.level = 1;                 // level 0 halves n_sub twice
+    T k3, k4, k12, q4;
+    glucose_rhs(p, x[3], x[4], x[12], T(0), cD, x[6], x[8], x[3] < T(0), x[3], k3, k4, k12, &q4);
+    t.level2 = tier_level2(p, u, x, t.f1, k3 + cD, q4);           // dx3 = dz3 + c R' (0 while x3 < 0)
     return t;
 }
 
-// One minute, step sizes by the rule, every lane taking its own level in place (generic kernels; the single-minute
-// kernel sets lanes of levels 1 and 2 aside instead and integrates them together at the end of the launch).
+// One minute, step sizes by the rule, every lane taking its own level in place.
 template <typename T, typename P, typename PR>
 __device__ __forceinline__ void split_minute_tiered(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub)
 {
-    const TierPre<T> t = tier_pre(p, u, x, n_sub);
-    if (t.level == 0) split_level<0, T, P, PR, true>(p, pr, u, x, n_sub, t.f1);
-    else if (t.level == 1) split_level<1, T, P, PR, true>(p, pr, u, x, n_sub, t.f1);
-    else split_level<2, T, P, PR, true>(p, pr, u, x, n_sub, t.f1);
+    const TierPre<T> t = tier_pre(p, u, x);
+    split_level<0, T, P, PR, true>(p, pr, u, x, n_sub, t.f1, t.level2);
 }
 
 template <int MATH, typename T, typename P>

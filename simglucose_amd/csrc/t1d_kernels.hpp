@@ -3,10 +3,10 @@
 //
 //   step1d_kernel      the headline launch: ONE simulated minute per env.step, split integrator with per-minute step
 //                      sizes.  One persistent workgroup per CU whose waves draw 64-env chunks from a queue in LDS; the
-//                      main pass integrates the calm lanes (level 0, ~95 %) and sets the others aside in two lists in
-//                      LDS, which the waves work off -- 64 at a time, every lane at the list's level -- once the queue is empty.
+//                      main pass integrates the lanes of level 1 and sets those of level 2 (~0.7 %) aside in a list in
+//                      LDS, which the waves work off -- 64 at a time, every lane at level 2 -- once the queue is empty.
 //   step1_kernel       the same launch with every lane integrated in place: the fixed-step form (level 1 everywhere),
-//                      tables of more than 32 patients, batches whose lists would not fit in LDS.
+//                      tables of more than 32 patients, batches whose list would not fit in LDS.
 //   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
 //                      integration -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
 //   refill_kernel      rebuilds due 150-minute CGM noise blocks ahead of a step kernel compiled without that code.
@@ -516,14 +516,13 @@ constexpr int kS1DThreads = 256 * T1D_S1D_WAVES;      // step1d_kernel
 //   0  level 1 for every lane (the fixed-step form of the scheme);
 //   1  step sizes by the rule, every lane its own level in place (split_minute_tiered);
 //   2  main pass of step1d_kernel: the rule is evaluated right after the meal bookkeeping and handed to
-//      on_level(level); lanes of level 0 integrate, the others stop there -- before anything of them is stored;
-//   3  pass of step1d_kernel over the listed lanes of level 1;
-//   4  ... of level 2.
+//      on_level(level 2?); lanes of level 1 integrate, the others stop there -- before anything of them is stored;
+//   3  pass of step1d_kernel over the listed lanes: every lane at level 2.
 template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONLEVEL>
 __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, ONLEVEL&& on_level,
                                          long long* tr, int tk)
 {
-    constexpr int LEVEL = MODE == 2 ? 0 : (MODE == 4 ? 2 : 1);        // the level this pass integrates at (modes 0, 2, 3, 4)
+    constexpr int LEVEL = MODE == 3 ? 2 : 1;                          // the level this pass integrates at (modes 0, 2, 3)
     (void)tr; (void)tk;
     S1_MARK(0);
     const BRows<T> X(a.x, a.n, kPackedRows);                // rows 0-12 x, 13 planned, 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_cgm, 18.. pts
@@ -560,10 +559,10 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
     T f1 = T(0);
     if (MODE == 2) {
-        const TierPre<T> tp = tier_pre(pl, u, e.x, a.n_sub);
+        const TierPre<T> tp = tier_pre(pl, u, e.x);
         f1 = tp.f1;
-        on_level(tp.level);
-        if (tp.level != 0) return;                   // nothing stored: the pass over its level's list redoes this lane from its loads
+        on_level(tp.level2);
+        if (tp.level2) return;                       // nothing stored: the pass over the list redoes this lane from its loads
     }
     // bookkeeping is final for this minute: store it now -- the meal words only where they changed (they do
     // while an env is eating, ~3 % of the minutes: 24 B per env-step of write traffic otherwise)
@@ -644,7 +643,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     S1_MARK(6);
 }
 
-struct S1NoLevel { __device__ __forceinline__ void operator()(int) const {} };
+struct S1NoLevel { __device__ __forceinline__ void operator()(bool) const {} };
 
 // tables of one CU, staged once per launch: ldp = [DP_COUNT][STRIDE], lpr = [prop_rows][STRIDE]
 template <typename T, int STRIDE>
@@ -719,19 +718,20 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
     }
 }
 
-// The single-minute launch with per-minute step sizes.  Taken in place (step1_kernel<.., true>) a wave runs at the
-// highest level among its lanes: ~3 % of the env-minutes of random-meal days are at level 1 and ~1.4 % at level 2,
-// so almost every wave would pay for level 1 and half of them for level 2 (3.5 x level 1): 185 us at 1 Mi envs.  Here
-// the main pass integrates the lanes of level 0 -- half the arithmetic of level 1 -- and a lane of another level only
-// leaves its env in that level's list in LDS (before anything of it is stored); waves that find the chunk queue empty
-// wait until every chunk of the CU is past that point and then take the listed envs 64 at a time, first the long
-// level 2, then level 1, from their loads, every lane at the list's level.  The lists hold every env of the CU's
-// share (t1d_step sizes them), so they cannot overflow; per-lane arithmetic is that of the in-place form, lane for lane.
-// (Tried and not kept -- git history: the level of an env's next minute evaluated at the end of the previous launch
-// and left in `meta`, so that the lists exist at launch start and are worked off next to the main pass: the gathers of
-// the listed envs then land in the cold first round of loads, 112 us instead of ~90.)
-// DREG: the list passes too take their parameters from VGPRs: they end the launch alone on their SIMDs, where LDS
-// round trips in the dependent chains count.
+// The single-minute launch with per-minute step sizes.  Taken in place (step1_kernel<.., true>) a wave with one lane of
+// level 2 runs the whole minute at level 2: 0.7 % of the env-minutes of random-meal days are at level 2, but a third of
+// the waves hold at least one.  Here the main pass integrates the lanes of level 1 with fixed steps (VGPR parameters, no
+// scratch) and a lane of level 2 only leaves its env in a list in LDS -- the decision needs nothing but the state at the
+// start of the minute and the first stage's kgut x1, which the integration then reuses, so it is taken right after the
+// meal bookkeeping, before anything of the lane is stored.  Waves that find the chunk queue empty wait until every chunk
+// of the CU is past that point and then take the listed envs 64 at a time, from their loads, every lane at level 2.  The
+// list holds every env of the CU's share (t1d_step sizes it), so it cannot overflow; per-lane arithmetic is that of the
+// in-place form, lane for lane.
+// (Built, measured and not kept in round 2 -- git history, DESIGN.md: a third, coarser level for calm minutes with two
+// lists -- the launch is bound by HBM, not arithmetic, and every listed env costs ~25 scattered 64-byte fetches -- and
+// the level of an env's NEXT minute left in `meta` by the previous launch, so that the lists exist at launch start.)
+// DREG: the list pass too takes its parameters from VGPRs: it ends the launch alone on its SIMDs, where LDS round trips
+// in the dependent chains count.
 template <typename T, bool EXTRA, bool DREG = false>
 __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
@@ -740,13 +740,12 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
     const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
     const unsigned lane = threadIdx.x & 63u;
-    // [per_block * 64] envs of level 1, as offsets from the workgroup's first env (< 65536: t1d_step), then those of level 2
-    uint16_t* const list1 = (uint16_t*)(lpr + a.prop_rows * STRIDE);
-    uint16_t* const list2 = list1 + per_block * 64;
-    __shared__ int queue, taken1, taken2, n1, n2, passed;
+    // [per_block * 64] envs of level 2, as offsets from the workgroup's first env (< 65536: t1d_step)
+    uint16_t* const list = (uint16_t*)(lpr + a.prop_rows * STRIDE);
+    __shared__ int queue, taken, listed, passed;
     __shared__ T lconst[8];
     s1_stage_tables<T, STRIDE>(a, ldp, lpr, lconst);
-    if (threadIdx.x == 0) { queue = 0; taken1 = 0; taken2 = 0; n1 = 0; n2 = 0; passed = 0; }
+    if (threadIdx.x == 0) { queue = 0; taken = 0; listed = 0; passed = 0; }
     __syncthreads();
     const int first = (int)blockIdx.x * per_block;
     const int count = nchunks - first < per_block ? nchunks - first : per_block;
@@ -776,9 +775,8 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
 #if T1D_S1_TRACE
             tr = ph ? ph + 16 : nullptr;                    // per-chunk phase marks of the wave's first six chunks
 #endif
-            s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, [&](int level) {
-                if (level == 1) list1[atomicAdd(&n1, 1)] = (uint16_t)(i - base);
-                else if (level == 2) list2[atomicAdd(&n2, 1)] = (uint16_t)(i - base);
+            s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, [&](bool level2) {
+                if (level2) list[atomicAdd(&listed, 1)] = (uint16_t)(i - base);
                 // lane 0 of a chunk is always a live env: it reports the chunk past its decision point, after the
                 // list entries of the wave (LDS operations of one wave execute in order)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -788,36 +786,26 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
     }
     tr = nullptr;
     S1D_PHASE(1);
-    // every chunk of this CU has been drawn; those still in flight may yet add to the lists
+    // every chunk of this CU has been drawn; those still in flight may yet add to the list
     while (__hip_atomic_load(&passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < count) __builtin_amdgcn_s_sleep(4);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    __builtin_amdgcn_s_setprio(3);                          // the launch ends with these passes: they go first on their SIMD
-    const int total2 = __hip_atomic_load(&n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const int total1 = __hip_atomic_load(&n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_setprio(3);                          // the launch ends with this pass: it goes first on its SIMD
+    const int total = __hip_atomic_load(&listed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     S1D_PHASE(2);
 #if T1D_S1_TRACE
-    if (ph && lane == 0) { ph[6] = total2; ph[7] = total1; ph[8] = it; }
+    if (ph && lane == 0) { ph[6] = total; ph[7] = 0; ph[8] = it; }
 #endif
     for (;;) {
-        const int lo = draw(&taken2) * 64;
-        if (lo >= total2) break;                            // wave-uniform
-        if (lo + (int)lane < total2) {
-            const unsigned i = base + (unsigned)list2[lo + (int)lane];
-            __builtin_assume(i < (1u << 28));
-            s1_chunk<DREG, T, STRIDE, EXTRA, 4>(a, ldp, lpr, lconst, i, S1NoLevel(), nullptr, 0);
-        }
-    }
-    S1D_PHASE(3);
-    for (;;) {
-        const int lo = draw(&taken1) * 64;
-        if (lo >= total1) break;                            // wave-uniform
-        if (lo + (int)lane < total1) {
-            const unsigned i = base + (unsigned)list1[lo + (int)lane];
+        const int lo = draw(&taken) * 64;
+        if (lo >= total) break;                             // wave-uniform
+        if (lo + (int)lane < total) {
+            const unsigned i = base + (unsigned)list[lo + (int)lane];
             __builtin_assume(i < (1u << 28));
             s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoLevel(), nullptr, 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
+    S1D_PHASE(3);
     S1D_PHASE(4);
 #undef S1D_PHASE
 }

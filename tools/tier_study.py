@@ -4,13 +4,13 @@ DOPRI5 path and a tight solve, and the share of env-minutes per level, on three 
   open   RandomScenario days with a new random basal rate every minute (what bench.py times), 1-minute sensor
   bb     closed loop with the BBController (boluses: EGP floor, renal threshold), Dexcom, 30 patients x seeds
   pid    closed loop with the reference test's PID gains (winds up: BG -> 0, the x3 >= 0 clamp), Dexcom
-usage: tier_study.py [open|bb|pid] [n_envs] [knob=value ...]     knobs: near move calm kink2 kink0 snap stiff0 stiff2"""
+usage: tier_study.py [open|bb|pid] [n_envs] [knob=value ...]     knobs: near move kink snap stiff"""
 import sys, time
 import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from oracle import t1d_oracle as O
 
-KNOBS = {"near": 0, "move": 1, "calm": 2, "kink2": 3, "kink0": 4, "snap": 5, "stiff0": 6, "stiff2": 7}
+KNOBS = {"near": 0, "move": 1, "kink": 2, "snap": 3, "stiff": 4}
 what = sys.argv[1] if len(sys.argv) > 1 else "open"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 for kv in sys.argv[3:]:
