@@ -95,22 +95,43 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores(cap=16):
+    """cores this process can actually keep busy: the cgroup's CPU quota where there is one (a GPU box hands a 16-core
+    share of a 256-thread host to each GPU: its affinity mask still shows every thread), else the affinity mask, and
+    never more than `cap` workers -- the baseline has to finish in seconds"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(n_envs, steps, n_sub, sensor, integ):
     """The CPU oracle (oracle/t1d_oracle.c: a from-scratch C port of the reference path running the SAME integrator as the
-    kernel) timed on a bounded sample of the same workload: one host core, then every core this process may use."""
+    kernel) timed on a bounded sample of the same workload: one host core, then the cores of this process's CPU share."""
     import multiprocessing as mp
     done, dt = _cpu_worker((n_envs, steps, n_sub, sensor, integ, 0))
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     out = {"value": done / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": "%d envs x %d steps, %s integrator n_sub=%d (same scheme as the kernel), fp64, 1 thread, %.1f s" % (n_envs, steps, integ, n_sub, dt),
            "cpu_model": cpu_model(), "cpu_count": os.cpu_count()}
     if cores > 1:
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(cores) as pool:
-            res = pool.map(_cpu_worker, [(n_envs, steps, n_sub, sensor, integ, 1 + k) for k in range(cores)])
+            res = pool.map(_cpu_worker, [(n_envs // 2, steps, n_sub, sensor, integ, 1 + k) for k in range(cores)])
         wall = time.perf_counter() - t0
         out["all_cores"] = {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env-steps/s", "cores": cores,
-                            "sample": "%d processes x (%d envs x %d steps), %.1f s wall incl. start-up" % (cores, n_envs, steps, wall)}
+                            "sample": "%d processes x (%d envs x %d steps), %.1f s wall incl. start-up" % (cores, n_envs // 2, steps, wall)}
     return out
 
 
@@ -187,7 +208,7 @@ def main(argv=None):
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
     ap.add_argument("--cpu-envs", type=int, default=32768)
-    ap.add_argument("--cpu-steps", type=int, default=600)
+    ap.add_argument("--cpu-steps", type=int, default=400)
     ap.add_argument("--plan-only", action="store_true", help="print this rank's shard plan as JSON and exit (no GPU; tests)")
     a = ap.parse_args(argv)
 

@@ -445,11 +445,12 @@ static hipError_t allow_lds(t1d_ctx* c, const void* fn, size_t bytes)
 
 // Which generic kernel variant a call takes (t1d_kernels.hpp): reference arithmetic, fast classical RK4, split at
 // level 1, split with per-minute step sizes in place.
-static int pick_variant(const t1d_ctx* c, bool split)
+static int pick_variant(const t1d_ctx* c, bool split, int dtype)
 {
     if (c->math == 0) return 0;
     if (!split) return 3;
-    return c->adaptive_gut ? 7 : 4;
+    if (!c->adaptive_gut) return 4;
+    return dtype == T1D_F32 ? 6 : 7;           // with per-lane step sizes the parameters fit in VGPRs in fp32 only
 }
 
 extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, void* stream)
@@ -470,7 +471,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         dyn = (size_t)kPropRows(n_sub) * c->np_pad * esz;
         if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_step: split tables exceed 64 KiB of LDS (n_patients x n_sub too large); use integrator 0");
     }
-    const int variant = pick_variant(c, split);
+    const int variant = pick_variant(c, split, b->dtype);
     const char* xb = (const char*)b->x;
     const size_t rowb = (size_t)b->n * esz;
     const bool packed = (const char*)b->planned == xb + 13 * rowb && (const char*)b->last_qsto == xb + 14 * rowb &&
@@ -528,12 +529,12 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         }
     }
 #define T1D_LAUNCH_STEP(V, TT, RF) hipLaunchKernelGGL((step_kernel<V, TT, RF>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
-#define T1D_BY_VARIANT(TT, RF) do { switch (variant) { case 0: T1D_LAUNCH_STEP(0, TT, RF); break; case 3: T1D_LAUNCH_STEP(3, TT, RF); break; \
-                                                       case 4: T1D_LAUNCH_STEP(4, TT, RF); break; default: T1D_LAUNCH_STEP(7, TT, RF); break; } } while (0)
+#define T1D_BY_VARIANT(TT, RF, V67) do { switch (variant) { case 0: T1D_LAUNCH_STEP(0, TT, RF); break; case 3: T1D_LAUNCH_STEP(3, TT, RF); break; \
+                                                            case 4: T1D_LAUNCH_STEP(4, TT, RF); break; default: T1D_LAUNCH_STEP(V67, TT, RF); break; } } while (0)
     if (split_refill) {          // the refill ran ahead (or none is due): the kernel compiled without it
-        if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, false); else T1D_BY_VARIANT(float, false);
+        if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, false, 7); else T1D_BY_VARIANT(float, false, 6);
     } else {
-        if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, true); else T1D_BY_VARIANT(float, true);
+        if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, true, 7); else T1D_BY_VARIANT(float, true, 6);
     }
 #undef T1D_BY_VARIANT
 #undef T1D_LAUNCH_STEP
@@ -590,13 +591,13 @@ static int launch_rollout(const char* who, t1d_ctx* c, const t1d_batch* b, int n
         dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
         if (dyn > 65536) return fail(T1D_E_INVALID, std::string(who) + ": split tables exceed 64 KiB of LDS; use integrator 0");
     }
-    const int variant = pick_variant(c, split);
+    const int variant = pick_variant(c, split, b->dtype);
 #define T1D_LAUNCH_ROLL(V, TT, MK) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, \
                                                       make_args<TT>(c, b, minutes, n_sub), MK())
-#define T1D_BY_VARIANT(TT, MK) do { switch (variant) { case 0: T1D_LAUNCH_ROLL(0, TT, MK); break; case 3: T1D_LAUNCH_ROLL(3, TT, MK); break; \
-                                                       case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; default: T1D_LAUNCH_ROLL(7, TT, MK); break; } } while (0)
-    if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, mk64);
-    else T1D_BY_VARIANT(float, mk32);
+#define T1D_BY_VARIANT(TT, MK, V67) do { switch (variant) { case 0: T1D_LAUNCH_ROLL(0, TT, MK); break; case 3: T1D_LAUNCH_ROLL(3, TT, MK); break; \
+                                                            case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; default: T1D_LAUNCH_ROLL(V67, TT, MK); break; } } while (0)
+    if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, mk64, 7);
+    else T1D_BY_VARIANT(float, mk32, 6);
 #undef T1D_BY_VARIANT
 #undef T1D_LAUNCH_ROLL
     T1D_HIP(hipGetLastError());

@@ -430,11 +430,12 @@ __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env
 //         3: fast arithmetic, classical RK4 evaluated sub-system by sub-system, parameters gathered once per lane into VGPRs
 //         4: fast arithmetic, split integrator at level 1 in every minute, VGPR parameters
 //         7: fast arithmetic, split integrator with per-minute step sizes taken in place, parameters from LDS
+//         6: as 7 with VGPR parameters (fp32, where they fit; fp64 spills)
 template <int VARIANT> struct VariantMath { static constexpr int value = VARIANT == 0 ? 0 : 1; };
 template <int VARIANT> struct VariantInfo {
-    static_assert(VARIANT == 0 || VARIANT == 3 || VARIANT == 4 || VARIANT == 7, "unknown kernel variant");
-    static constexpr bool split = VARIANT == 4 || VARIANT == 7;
-    static constexpr bool tiered = VARIANT == 7;
+    static_assert(VARIANT == 0 || VARIANT == 3 || VARIANT == 4 || VARIANT == 6 || VARIANT == 7, "unknown kernel variant");
+    static constexpr bool split = VARIANT == 4 || VARIANT == 6 || VARIANT == 7;
+    static constexpr bool tiered = VARIANT == 6 || VARIANT == 7;
     static constexpr bool lds_pars = VARIANT == 0 || VARIANT == 7;
 };
 extern __shared__ __align__(16) unsigned char t1d_dyn_lds[];
@@ -459,10 +460,10 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
     const T rp = prev_risk<MATH>(a, e.prev_cgm);
     StepOut<T> o;
-    if constexpr (VARIANT == 4) {
+    if constexpr (VARIANT == 4 || VARIANT == 6) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
-        o = step_body<MATH, T, ParsReg<T>, REFILL, PropLds<T>, false>(a, p, i, e, basal, bolus, a.bolus != nullptr, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
+        o = step_body<MATH, T, ParsReg<T>, REFILL, PropLds<T>, VARIANT == 6>(a, p, i, e, basal, bolus, a.bolus != nullptr, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
     } else if constexpr (VARIANT == 7) {
         ParsLds<T> p{lds, (int)pid};
         o = step_body<MATH, T, ParsLds<T>, REFILL, PropLds<T>, true>(a, p, i, e, basal, bolus, a.bolus != nullptr, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
@@ -527,20 +528,22 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     S1_MARK(0);
     const BRows<T> X(a.x, a.n, kPackedRows);                // rows 0-12 x, 13 planned, 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_cgm, 18.. pts
     const BRows<int32_t> I(a.t, a.n, 3);                    // rows t, meta, next_meal
+    // what the pump, the meal bookkeeping and the step-size rule's gut part need is requested first: loads return in
+    // order, so that work starts while the other eleven state rows are still on their way
     const uint32_t meta = (uint32_t)(int32_t)at(I(1), i);
-    const uint32_t pid = T1D_META_PID(meta);
     Env<T> e;
-#pragma unroll
-    for (int k = 0; k < 13; ++k) e.x[k] = at(X(k), i);
-    e.planned = at(X(13), i); e.lq = at(X(14), i); e.lf = at(X(15), i);
-    const T planned0 = e.planned, lq0 = e.lq, lf0 = e.lf;
     e.t = at(I(0), i);
     e.next_meal = at(I(2), i);
+    const T basal = at(a.basal, i);
+    const T bolus = a.bolus ? at(a.bolus, i) : T(0);
+    e.planned = at(X(13), i); e.lq = at(X(14), i); e.lf = at(X(15), i);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) e.x[k] = at(X(k), i);
+    const uint32_t pid = T1D_META_PID(meta);
+    const T planned0 = e.planned, lq0 = e.lq, lf0 = e.lf;
     e.next_meal_loaded = e.next_meal;
     e.eating = (meta & T1D_META_EATING) != 0;
     e.cursor = (int)T1D_META_CURSOR(meta);
-    const T basal = at(a.basal, i);
-    const T bolus = a.bolus ? at(a.bolus, i) : T(0);
     S1_MARK(1);
     T q_basal, q_bolus;
     if (a.flags & T1D_BATCH_NO_PUMP) {
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void rollout_pid_kernel(const KA
     const uint32_t pid = T1D_META_PID(meta);
     Env<T> e;
     load_env(a, i, meta, e);
-    if constexpr (VARIANT == 4) {
+    if constexpr (VARIANT == 4 || VARIANT == 6) {
         ParsReg<T> p;
         p.load(a.dpar, (int)pid);
         rollout_body<VARIANT>(a, c, p, i, pid, e, PropLds<T>{(const T*)t1d_dyn_lds, a.np_pad, (int)pid});
