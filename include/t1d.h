@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define T1D_ABI_VERSION 2
+#define T1D_ABI_VERSION 3
 
 enum { T1D_F64 = 0, T1D_F32 = 1 };
 
@@ -106,7 +106,7 @@ typedef struct t1d_batch {
     uint64_t seed;            /* Philox key */
     /* ---- state (read + written by t1d_step; written by t1d_reset).
      * PACKED layout (recommended; detected from the pointers): x, planned, last_qsto, last_food, last_cgm,
-     * prev_cgm, pts are consecutive rows of ONE [44][n] buffer in that order, and t, meta, next_meal are
+     * prev_risk, pts are consecutive rows of ONE [44][n] buffer in that order, and t, meta, next_meal are
      * consecutive rows of one [3][n] int32 buffer.  With it one-minute launches (minutes == 1) take the
      * persistent single-minute kernels; any other layout runs the generic step kernel. */
     void* x;                  /* [13][n] ODE state */
@@ -121,11 +121,12 @@ typedef struct t1d_batch {
                                  t1d_reset/t1d_step so the common minute needs no table access.  NULL = the
                                  table row at the cursor is read every minute instead */
     void* last_cgm;           /* [n] sensor zero-order hold (cgm.py:32-36); never read with a 1-minute sensor, and then
-                               * not maintained by one-minute launches (the observation is in cgm / prev_cgm) */
+                               * not maintained by one-minute launches (the observation is in cgm) */
     void* ar_e;               /* [n] AR(1) noise state      (noise_gen.py:86-88) */
     void* pts;                /* [26][n] CGM-noise spline of the current 150-min block: rows 0-10 the Johnson-SU
                                  points, 11-21 their knot second derivatives, 22-25 the current 15-min interval */
-    void* prev_cgm;           /* [n] CGM_hist[-1] (default reward, env.py:27-33) */
+    void* prev_risk;          /* [n] risk index of CGM_hist[-1]: the default reward risk_diff (env.py:27-33) is
+                               * risk(CGM_hist[-2]) - risk(CGM_hist[-1]); its first term is the second term of the step before */
     /* ---- inputs */
     const void* basal;        /* [n] U/min */
     const void* bolus;        /* [n] U/min, NULL = 0 */
@@ -135,7 +136,7 @@ typedef struct t1d_batch {
     const void* meal_amt;     /* [n_meals][n] grams */
     const void* normals;      /* [n_normals][n] standard normals in draw order (exact-parity mode) */
     const void* x0_override;  /* [13][n] initial state for t1d_reset, NULL = table x0 */
-    /* ---- outputs (any of lbgi..insulin may be NULL) */
+    /* ---- outputs (any of lbgi..cgm0 may be NULL) */
     void* cgm;                /* [n] observation: mean CGM over the step (env.py:81) */
     void* bg;                 /* [n] mean Gsub over the step (env.py:80) */
     void* reward;             /* [n] risk_diff */
@@ -143,6 +144,7 @@ typedef struct t1d_batch {
     void* lbgi; void* hbgi; void* risk;   /* [n] risk_index([bg], 1) */
     void* meal;               /* [n] mean announced CHO (env.py:78) */
     void* insulin;            /* [n] mean pump output (env.py:79) */
+    void* cgm0;               /* [n] written by t1d_reset only: CGM sample #0, the CGM_hist[0] of env.py:126 (may be NULL) */
 } t1d_batch;
 
 typedef struct t1d_pid {
@@ -240,7 +242,7 @@ int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 int t1d_split_tables(const double* patient_row, int n_cols, int n_sub, double* out, int out_len);
 
 /* Reset the envs whose mask byte is non-zero (mask == NULL: all).  Outputs as after
- * T1DSimEnv.reset(): cgm = CGM sample #1, prev_cgm = CGM sample #0, bg/lbgi/hbgi/risk of the
+ * T1DSimEnv.reset(): cgm = CGM sample #1, cgm0 = CGM sample #0 (prev_risk = its risk index), bg/lbgi/hbgi/risk of the
  * initial state, reward 0, done 0.  random_init_bg != 0 draws x[3], x[4], x[12] ~ N(mu, 0.1 mu)
  * with Philox (statistical counterpart of t1dpatient.py:256-270; exact parity = x0_override). */
 int t1d_reset(t1d_ctx* ctx, const t1d_batch* b, const uint8_t* mask, int random_init_bg, void* hip_stream);

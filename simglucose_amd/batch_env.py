@@ -15,8 +15,8 @@ import torch
 from . import _lib, params
 
 _STATE_KEYS = ("x", "planned", "last_qsto", "last_food", "t", "meta", "episode", "next_meal", "last_cgm", "ar_e",
-               "pts", "prev_cgm")
-_OUT_KEYS = ("cgm", "bg", "reward", "done", "lbgi", "hbgi", "risk", "meal", "insulin")
+               "pts", "prev_risk")
+_OUT_KEYS = ("cgm", "bg", "reward", "done", "lbgi", "hbgi", "risk", "meal", "insulin", "cgm0")
 
 
 class BatchedT1DSimEnv:
@@ -94,7 +94,7 @@ class BatchedT1DSimEnv:
         # tensors are views, so every staged row is one base pointer plus a 32-bit offset on the device
         self.state = z(44, n)
         self.x = self.state[0:13]; self.planned = self.state[13]; self.last_qsto = self.state[14]
-        self.last_food = self.state[15]; self.last_cgm = self.state[16]; self.prev_cgm = self.state[17]
+        self.last_food = self.state[15]; self.last_cgm = self.state[16]; self.prev_risk = self.state[17]
         self.pts = self.state[18:44]
         self.istate = z(4, n, dt=torch.int32)
         self.t = self.istate[0]; self.meta = self.istate[1]; self.next_meal = self.istate[2]; self.episode = self.istate[3]
@@ -102,6 +102,7 @@ class BatchedT1DSimEnv:
         self.next_meal.fill_(_lib.MEAL_UNUSED)
         self.ar_e = z(n)
         self.cgm = z(n); self.bg = z(n); self.reward = z(n); self.done = z(n, dt=torch.uint8)
+        self.cgm0 = z(n)                   # CGM sample #0 of the current episode (CGM_hist[0]); written by reset only
         if extra_outputs:
             self.lbgi = z(n); self.hbgi = z(n); self.risk = z(n); self.meal = z(n); self.insulin = z(n)
         else:
@@ -182,14 +183,14 @@ class BatchedT1DSimEnv:
             self._hist_cnt = torch.zeros(self.n, dtype=torch.int64, device=self.device)
 
     def _hist_reset(self, mask):
-        """T1DSimEnv._reset: CGM_hist = [sample #0] (env.py:126), which the reset kernel leaves in prev_cgm"""
+        """T1DSimEnv._reset: CGM_hist = [sample #0] (env.py:126), which the reset kernel leaves in cgm0"""
         if self._hist is None:
             return
         m = torch.ones(self.n, dtype=torch.bool, device=self.device) if mask is None else mask.bool()
         self._hist[:, m] = float("nan")
         self._hist_pos[m] = 0
         self._hist_cnt[m] = 1
-        self._hist[0, m] = self.prev_cgm[m]
+        self._hist[0, m] = self.cgm0[m]
 
     def _hist_push(self):
         """CGM_hist.append(CGM) (env.py:94) for every env"""
@@ -313,7 +314,7 @@ class BatchedT1DSimEnv:
         if "bg" in tr:
             tr["bg"][0] = self.bg
         if "cgm" in tr:
-            tr["cgm"][0] = self.prev_cgm
+            tr["cgm"][0] = self.cgm0
         return tr
 
     def rollout_pid(self, n_steps, P, I, D, target=140.0, pid_state=None, stats=None, trace=None):
@@ -420,13 +421,13 @@ class BatchedT1DSimEnv:
 
     # ------------------------------------------------------------------ checkpoint
     def state_dict(self):
-        sd = {k: getattr(self, k).clone() for k in _STATE_KEYS + ("cgm",)}
+        sd = {k: getattr(self, k).clone() for k in _STATE_KEYS + ("cgm", "cgm0")}
         if self._hist is not None:
             sd.update({k: getattr(self, k).clone() for k in ("_hist", "_hist_pos", "_hist_cnt")})
         return sd
 
     def load_state_dict(self, sd):
-        for k in _STATE_KEYS + ("cgm",):
+        for k in _STATE_KEYS + ("cgm", "cgm0"):
             getattr(self, k).copy_(sd[k])
         for k in ("_hist", "_hist_pos", "_hist_cnt"):
             if getattr(self, k) is not None and k in sd:

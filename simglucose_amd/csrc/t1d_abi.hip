@@ -371,7 +371,7 @@ static int check_batch(const char* who, const t1d_ctx* c, const t1d_batch* b, bo
         return fail(T1D_E_INVALID, std::string(who) + ": batch.n out of range");
     if (b->dtype != T1D_F64 && b->dtype != T1D_F32) return fail(T1D_E_INVALID, std::string(who) + ": bad dtype");
     if (!b->x || !b->planned || !b->last_qsto || !b->last_food || !b->t || !b->meta || !b->last_cgm ||
-        !b->ar_e || !b->pts || !b->prev_cgm)
+        !b->ar_e || !b->pts || !b->prev_risk)
         return fail(T1D_E_INVALID, std::string(who) + ": a state pointer is NULL");
     if (!b->cgm || !b->bg || !b->reward || !b->done)
         return fail(T1D_E_INVALID, std::string(who) + ": cgm/bg/reward/done outputs are required");
@@ -395,13 +395,13 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.n = b->n; a.env_offset = b->env_offset; a.seed = b->seed;
     a.x = (T*)b->x; a.planned = (T*)b->planned; a.last_qsto = (T*)b->last_qsto; a.last_food = (T*)b->last_food;
     a.t = b->t; a.meta = b->meta; a.episode = b->episode; a.next_meal = b->next_meal;
-    a.last_cgm = (T*)b->last_cgm; a.ar_e = (T*)b->ar_e; a.pts = (T*)b->pts; a.prev_cgm = (T*)b->prev_cgm;
+    a.last_cgm = (T*)b->last_cgm; a.ar_e = (T*)b->ar_e; a.pts = (T*)b->pts; a.prev_risk = (T*)b->prev_risk;
     a.basal = (const T*)b->basal; a.bolus = (const T*)b->bolus; a.cho = (const T*)b->cho;
     a.meal_time = b->meal_time; a.meal_amt = (const T*)b->meal_amt;
     a.normals = b->n_normals > 0 ? (const T*)b->normals : nullptr;
     a.x0_override = (const T*)b->x0_override;
     a.cgm = (T*)b->cgm; a.bg = (T*)b->bg; a.reward = (T*)b->reward; a.done = b->done;
-    a.lbgi = (T*)b->lbgi; a.hbgi = (T*)b->hbgi; a.risk = (T*)b->risk; a.meal = (T*)b->meal; a.insulin = (T*)b->insulin;
+    a.lbgi = (T*)b->lbgi; a.hbgi = (T*)b->hbgi; a.risk = (T*)b->risk; a.meal = (T*)b->meal; a.insulin = (T*)b->insulin; a.cgm0 = (T*)b->cgm0;
     a.dpar = sizeof(T) == 8 ? (const T*)c->d_par64 : (const T*)c->d_par32;
     a.x0tab = c->d_x0;
     a.minv = sizeof(T) == 8 ? (const T*)c->d_minv64 : (const T*)c->d_minv32;
@@ -476,7 +476,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     const size_t rowb = (size_t)b->n * esz;
     const bool packed = (const char*)b->planned == xb + 13 * rowb && (const char*)b->last_qsto == xb + 14 * rowb &&
                         (const char*)b->last_food == xb + 15 * rowb && (const char*)b->last_cgm == xb + 16 * rowb &&
-                        (const char*)b->prev_cgm == xb + 17 * rowb && (const char*)b->pts == xb + 18 * rowb &&
+                        (const char*)b->prev_risk == xb + 17 * rowb && (const char*)b->pts == xb + 18 * rowb &&
                         b->next_meal && (const char*)b->meta == (const char*)b->t + (size_t)b->n * 4 &&
                         (const char*)b->next_meal == (const char*)b->t + (size_t)b->n * 8 &&
                         (size_t)kPackedRows * rowb < ((size_t)1 << 32);

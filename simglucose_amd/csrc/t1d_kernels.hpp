@@ -41,10 +41,10 @@ template <typename T> struct KArgs {
     int64_t n, env_offset;
     uint64_t seed;
     T* x; T* planned; T* last_qsto; T* last_food; int32_t* t; uint32_t* meta; uint32_t* episode; int32_t* next_meal;
-    T* last_cgm; T* ar_e; T* pts; T* prev_cgm;
+    T* last_cgm; T* ar_e; T* pts; T* prev_risk;
     const T* basal; const T* bolus; const T* cho; const int32_t* meal_time; const T* meal_amt;
     const T* normals; const T* x0_override;
-    T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin;
+    T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin; T* cgm0;
     const T* dpar;          // [DP_COUNT][kMaxPatients] derived patient constants
     const T* prop;          // [prop_rows][np_pad] insulin propagator of the split integrator (kPropRows(n_sub) rows)
     const double* x0tab;    // [13][np]
@@ -134,7 +134,7 @@ template <typename U> __device__ __forceinline__ BRef<U> at(BRow<U> row, unsigne
 // env state held in registers across the minutes of a launch
 template <typename T> struct Env {
     T x[13];
-    T planned, lq, lf, last_cgm, prev_cgm;
+    T planned, lq, lf, last_cgm, prev_risk;   // prev_risk: risk index of CGM_hist[-1]
     T cur[4];           // current 15-min interval of the noise spline (pts rows 22..25)
     int t, cursor, next_meal, next_meal_loaded;
     bool eating;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void load_env(const KArgs<T>& a, unsigned i, uint32_t
 #pragma unroll
     for (int k = 0; k < 13; ++k) e.x[k] = at(row(a.x, a.n, k), i);
     e.planned = at(a.planned, i); e.lq = at(a.last_qsto, i); e.lf = at(a.last_food, i);
-    e.last_cgm = at(a.last_cgm, i); e.prev_cgm = at(a.prev_cgm, i);
+    e.last_cgm = at(a.last_cgm, i); e.prev_risk = at(a.prev_risk, i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) e.cur[k] = at(row(a.pts, a.n, 22 + k), i);
     e.t = at(a.t, i);
@@ -180,7 +180,7 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
 #pragma unroll
     for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
     at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
-    at(a.last_cgm, i) = e.last_cgm; at(a.prev_cgm, i) = e.prev_cgm;
+    at(a.last_cgm, i) = e.last_cgm; at(a.prev_risk, i) = e.prev_risk;
     at(a.t, i) = e.t;
     if (a.next_meal && e.next_meal != e.next_meal_loaded) at(a.next_meal, i) = e.next_meal;
     at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
@@ -396,23 +396,15 @@ __device__ __forceinline__ StepOut<T> step_body(const KArgs<T>& a, P& p, unsigne
     return o;
 }
 
-// risk of CGM_hist[-1] (risk_diff, env.py:27-33): independent of this step's integration, so callers
-// evaluate it BEFORE the minute loop, where it overlaps with the pump / meal / noise chains
-template <int MATH, typename T>
-__device__ __forceinline__ T prev_risk(const KArgs<T>& a, T prev_cgm)
-{
-    T l, h, rp = T(0);
-    if (!ab_flag(a, 0x100)) risk_index1<MATH>(prev_cgm, l, h, rp);
-    return rp;
-}
-
+// The default reward (risk_diff, env.py:27-33) is risk(CGM_hist[-2]) - risk(CGM_hist[-1]): the first term is the
+// second term of the previous step, so it travels with the env state (prev_risk) instead of being evaluated again.
 template <int MATH, typename T>
 __device__ __forceinline__ void write_outputs(const KArgs<T>& a, unsigned i, Env<T>& e, const StepOut<T>& o, T rp)
 {
     T l, h, r, rc = T(0);
     if (!ab_flag(a, 0x100)) risk_index1<MATH>(o.cgm, l, h, rc);
     at(a.reward, i) = rp - rc;
-    e.prev_cgm = o.cgm;
+    e.prev_risk = rc;
     at(a.cgm, i) = o.cgm; at(a.bg, i) = o.bg;
     at(a.done, i) = (o.bg < T(70) || o.bg > T(350)) ? 1 : 0;  // env.py:103
     if (a.lbgi || a.hbgi || a.risk) {
@@ -458,7 +450,7 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
     load_env(a, i, meta, e);
     const T basal = at(a.basal, i);
     const T bolus = a.bolus ? at(a.bolus, i) : T(0);
-    const T rp = prev_risk<MATH>(a, e.prev_cgm);
+    const T rp = e.prev_risk;
     StepOut<T> o;
     if constexpr (VARIANT == 4 || VARIANT == 6) {
         ParsReg<T> p;
@@ -496,8 +488,12 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
 #ifndef T1D_S1_TRACE
 #define T1D_S1_TRACE 0
 #endif
-#ifndef T1D_S1_ROTATE_PRIO
-#define T1D_S1_ROTATE_PRIO 1
+// issue priority of a wave outside its integration (0 = leave priorities alone).  The integration is pure arithmetic;
+// everything else leads to a chunk's stores and to the next chunk's loads, and a wave held up there leaves the memory
+// system idle: those phases go first on the SIMD, the integrations of the other waves fill the slots they leave
+// (1 Mi envs fp64: 84.8 -> 83.0 us; rotating the priority among the waves chunk by chunk instead: 85.5).
+#ifndef T1D_S1_PHASE_PRIO
+#define T1D_S1_PHASE_PRIO 3
 #endif
 #if T1D_S1_TRACE
 // tuning builds: drain every counter and stamp the wall clock (100 MHz) at phase boundaries
@@ -509,6 +505,9 @@ constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a C
 #ifndef T1D_S1D_WAVES
 #define T1D_S1D_WAVES 3
 #endif
+#ifndef T1D_S1D_PREFETCH
+#define T1D_S1D_PREFETCH 0
+#endif
 constexpr int kS1DThreads = 256 * T1D_S1D_WAVES;      // step1d_kernel
 // EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
 // third risk evaluation drop out of the kernel altogether
@@ -519,26 +518,46 @@ constexpr int kS1DThreads = 256 * T1D_S1D_WAVES;      // step1d_kernel
 //   2  main pass of step1d_kernel: the rule is evaluated right after the meal bookkeeping and handed to
 //      on_level(level 2?); lanes of level 1 integrate, the others stop there -- before anything of them is stored;
 //   3  pass of step1d_kernel over the listed lanes: every lane at level 2.
+// what a chunk reads before its integration
+template <typename T> struct S1In { uint32_t meta; int t, next_meal; T basal, bolus, planned, lq, lf, x[13]; };
+
+template <typename T>
+__device__ __forceinline__ S1In<T> s1_load(const KArgs<T>& a, unsigned i)
+{
+    const BRows<T> X(a.x, a.n, kPackedRows);
+    const BRows<int32_t> I(a.t, a.n, 3);
+    S1In<T> in;
+    // what the pump, the meal bookkeeping and the step-size rule's gut part need is requested first: loads return in
+    // order, so that work starts while the other eleven state rows are still on their way
+    in.meta = (uint32_t)(int32_t)at(I(1), i);
+    in.t = at(I(0), i);
+    in.next_meal = at(I(2), i);
+    in.basal = at(a.basal, i);
+    in.bolus = a.bolus ? (T)at(a.bolus, i) : T(0);
+    in.planned = at(X(13), i); in.lq = at(X(14), i); in.lf = at(X(15), i);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) in.x[k] = at(X(k), i);
+    return in;
+}
+
 template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONLEVEL>
-__device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, ONLEVEL&& on_level,
-                                         long long* tr, int tk)
+__device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, const S1In<T>& in,
+                                         ONLEVEL&& on_level, long long* tr, int tk)
 {
     constexpr int LEVEL = MODE == 3 ? 2 : 1;                          // the level this pass integrates at (modes 0, 2, 3)
     (void)tr; (void)tk;
     S1_MARK(0);
-    const BRows<T> X(a.x, a.n, kPackedRows);                // rows 0-12 x, 13 planned, 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_cgm, 18.. pts
+    const BRows<T> X(a.x, a.n, kPackedRows);                // rows 0-12 x, 13 planned, 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_risk, 18.. pts
     const BRows<int32_t> I(a.t, a.n, 3);                    // rows t, meta, next_meal
-    // what the pump, the meal bookkeeping and the step-size rule's gut part need is requested first: loads return in
-    // order, so that work starts while the other eleven state rows are still on their way
-    const uint32_t meta = (uint32_t)(int32_t)at(I(1), i);
+    const uint32_t meta = in.meta;
     Env<T> e;
-    e.t = at(I(0), i);
-    e.next_meal = at(I(2), i);
-    const T basal = at(a.basal, i);
-    const T bolus = a.bolus ? at(a.bolus, i) : T(0);
-    e.planned = at(X(13), i); e.lq = at(X(14), i); e.lf = at(X(15), i);
+    e.t = in.t;
+    e.next_meal = in.next_meal;
+    const T basal = in.basal;
+    const T bolus = in.bolus;
+    e.planned = in.planned; e.lq = in.lq; e.lf = in.lf;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) e.x[k] = at(X(k), i);
+    for (int k = 0; k < 13; ++k) e.x[k] = in.x[k];
     const uint32_t pid = T1D_META_PID(meta);
     const T planned0 = e.planned, lq0 = e.lq, lf0 = e.lf;
     e.next_meal_loaded = e.next_meal;
@@ -583,6 +602,9 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         if (a.insulin) at(a.insulin, i) = insulin;
     }
     S1_MARK(2);
+#if T1D_S1_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(0);                   // the integration fills the issue slots the other phases leave
+#endif
     if (!ab_flag(a, 0x800)) {
         PropLdsS<T, STRIDE> pr{lpr, (int)pid};
         if (MODE == 1) {
@@ -600,6 +622,9 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         }
     }
     S1_MARK(3);
+#if T1D_S1_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(T1D_S1_PHASE_PRIO);   // what leads to this chunk's stores and the next chunk's loads goes first
+#endif
 #pragma unroll
     for (int k = 0; k < 13; ++k) at(X(k), i) = e.x[k];
     // the sensor side is fetched only now: nothing of it has to stay in registers across the integration
@@ -607,7 +632,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     for (int k = 0; k < 4; ++k) e.cur[k] = at(X(40 + k), i);
     // with a 1-minute sensor every minute takes a fresh sample: the held value is never read
     T last_cgm = a.sen.st == 1 ? T(0) : (T)at(X(16), i);
-    const T prev_cgm = at(X(17), i);
+    const T rp = at(X(17), i);                                // risk index of the previous step's CGM
     S1_MARK(4);
     bool due, entered = false;
     const T noise = measure_noise<false>(a, i, e, due, &entered);       // e.t is still the minute's start: sample for t + 1
@@ -615,7 +640,6 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
 #pragma unroll
         for (int k = 0; k < 4; ++k) at(X(40 + k), i) = e.cur[k];
     }
-    const T rp = prev_risk<1>(a, prev_cgm);
     const T gsub = e.x[12] * pl(DP_IVG);                                                       // t1dpatient.py:217-218
     if (due) {                                                                                 // cgm.py:26-36
         T c = gsub + noise;
@@ -630,7 +654,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     T l, h, r, rc = T(0);
     if (!ab_flag(a, 0x100)) risk_index1<1>(last_cgm, l, h, rc);
     at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
-    at(X(17), i) = last_cgm;
+    at(X(17), i) = rc;
     at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
     at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
     if (EXTRA && (a.lbgi || a.hbgi || a.risk)) {
@@ -667,24 +691,12 @@ __device__ __forceinline__ void s1_stage_tables(const KArgs<T>& a, T* ldp, T* lp
     }
 }
 
-// rotate the issue priority among the waves of a SIMD (waves w, w + 4, w + 8 of the workgroup) chunk by chunk
-__device__ __forceinline__ void s1_rotate_prio(int it)
-{
-#if T1D_S1_ROTATE_PRIO
-    switch ((unsigned)(it + (int)(threadIdx.x >> 8)) % 3u) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        default: __builtin_amdgcn_s_setprio(2); break;
-    }
-#endif
-}
-
 // every lane in place: TIERED = step sizes by the rule (LDS parameters), else level 1 everywhere (VGPR parameters)
 template <typename T, int STRIDE, bool EXTRA, bool TIERED>
 __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
-    // prev_cgm and the 26 noise rows; rows 1, 2 of the t buffer are meta and next_meal.  Deriving them from two
+    // prev_risk and the 26 noise rows; rows 1, 2 of the t buffer are meta and next_meal.  Deriving them from two
     // base pointers instead of reading ten more kernel arguments keeps the scalar registers from spilling.
     T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
@@ -716,8 +728,7 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         __builtin_assume(i < (1u << 28));
         if ((int64_t)i >= a.n) continue;
         ++tk;
-        s1_rotate_prio(it);
-        s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, S1NoLevel(), tr, tk);
+        s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), tr, tk);
     }
 }
 
@@ -767,26 +778,48 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
         if (lane == 0) g = atomicAdd(counter, 1);
         return __builtin_amdgcn_readfirstlane(g);
     };
+    auto on_level = [&](unsigned i) {
+        return [&, i](bool level2) {
+            if (level2) list[atomicAdd(&listed, 1)] = (uint16_t)(i - base);
+            // lane 0 of a chunk is always a live env: it reports the chunk past its decision point, after the
+            // list entries of the wave (LDS operations of one wave execute in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&passed, 1);
+        };
+    };
     int it = 0;
+#if T1D_S1D_PREFETCH
+    // the loads of a wave's next chunk are issued before the integration of the current one
+    {
+        int c = draw(&queue);
+        unsigned i = (unsigned)(first + c) * 64u + lane;
+        S1In<T> cur;
+        if (c < count && (int64_t)i < a.n) cur = s1_load(a, i);
+        while (c < count) {
+            const int c2 = draw(&queue);
+            const unsigned i2 = (unsigned)(first + c2) * 64u + lane;
+            __builtin_assume(i < (1u << 28));
+            __builtin_assume(i2 < (1u << 28));
+            S1In<T> nxt;
+            if (c2 < count && (int64_t)i2 < a.n) nxt = s1_load(a, i2);
+            if ((int64_t)i < a.n) s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, cur, on_level(i), tr, it);
+            cur = nxt; c = c2; i = i2; ++it;
+        }
+    }
+#else
     for (;; ++it) {
         const int c = draw(&queue);
         if (c >= count) break;                              // wave-uniform
         const unsigned i = (unsigned)(first + c) * 64u + lane;
         __builtin_assume(i < (1u << 28));
-        s1_rotate_prio(it);
         if ((int64_t)i < a.n) {
 #if T1D_S1_TRACE
             tr = ph ? ph + 16 : nullptr;                    // per-chunk phase marks of the wave's first six chunks
 #endif
-            s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, [&](bool level2) {
-                if (level2) list[atomicAdd(&listed, 1)] = (uint16_t)(i - base);
-                // lane 0 of a chunk is always a live env: it reports the chunk past its decision point, after the
-                // list entries of the wave (LDS operations of one wave execute in order)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) atomicAdd(&passed, 1);
-            }, tr, it);
+            s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, s1_load(a, i), on_level(i), tr, it);
         }
     }
+#endif
     tr = nullptr;
     S1D_PHASE(1);
     // every chunk of this CU has been drawn; those still in flight may yet add to the list
@@ -804,7 +837,7 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
         if (lo + (int)lane < total) {
             const unsigned i = base + (unsigned)list[lo + (int)lane];
             __builtin_assume(i < (1u << 28));
-            s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, S1NoLevel(), nullptr, 0);
+            s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), nullptr, 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
@@ -850,7 +883,7 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
     int n_low = c.n_low ? at(c.n_low, i) : 0, n_high = c.n_high ? at(c.n_high, i) : 0;
     const T st = T(a.sen.st);
     StepOut<T> o{obs, T(0), T(0), T(0)};
-    T pre_prev_cgm = e.prev_cgm;
+    T cgm_before = T(0);                        // CGM of the step before the last one, once two steps have run
     for (int s = 0; s < c.n_steps; ++s) {
         T u, bolus = T(0);
         if (bb) {
@@ -873,15 +906,16 @@ __device__ __forceinline__ void rollout_body(const KArgs<T>& a, const PidArgs<T>
         if (c.cgm_trace) c.cgm_trace[(c.trace_row + s) * a.n + i] = o.cgm;
         if (c.cho_trace) c.cho_trace[(c.trace_row + s) * a.n + i] = o.meal;
         if (c.ins_trace) c.ins_trace[(c.trace_row + s) * a.n + i] = o.ins;
-        pre_prev_cgm = e.prev_cgm;
-        e.prev_cgm = o.cgm;                      // CGM history advances every step
+        if (s + 1 < c.n_steps) cgm_before = o.cgm;  // CGM history advances every step
         if (c.sum_risk) { T l, h, r; risk_index1<MATH>(o.bg, l, h, r); sum_risk += r; }
         min_bg = o.bg < min_bg ? o.bg : min_bg;
         max_bg = o.bg > max_bg ? o.bg : max_bg;
         n_low += o.bg < T(70); n_high += o.bg > T(180);
     }
-    e.prev_cgm = pre_prev_cgm;                   // the last step's reward is formed from it
-    write_outputs<MATH>(a, i, e, o, prev_risk<MATH>(a, pre_prev_cgm));
+    // the last step's reward: against the step before it, or against what the state carried in (one step)
+    T rp = e.prev_risk;
+    if (c.n_steps > 1) { T l, h; risk_index1<MATH>(cgm_before, l, h, rp); }
+    write_outputs<MATH>(a, i, e, o, rp);
     store_env(a, i, pid, e);
     if (bb) at(c.bb_prev_meal, i) = prev_meal;
     else { at(c.integ, i) = integ; at(c.prev, i) = prev; }
@@ -970,7 +1004,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
         c[s] = v;
     }
     e.last_cgm = c[1];
-    e.prev_cgm = c[0];
+    { T l0, h0; risk_index1<0>(c[0], l0, h0, e.prev_risk); }    // CGM_hist = [sample #0]: what the first reward is formed against
+    if (a.cgm0) at(a.cgm0, i) = c[0];
     store_env(a, i, pid, e);
     T l, h, r;
     risk_index1<0>(bg0, l, h, r);

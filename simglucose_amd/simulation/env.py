@@ -89,7 +89,7 @@ class T1DSimEnv(object):
         b = self._batch
         self.time_hist = [self.scenario.start_time]
         self.BG_hist = [self._scalar("bg")]
-        self.CGM_hist = [float(b.prev_cgm[0])]        # sample #0 (env.py:126)
+        self.CGM_hist = [float(b.cgm0[0])]        # sample #0 (env.py:126)
         self.risk_hist = [self._scalar("risk")]
         self.LBGI_hist = [self._scalar("lbgi")]
         self.HBGI_hist = [self._scalar("hbgi")]

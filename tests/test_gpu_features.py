@@ -108,7 +108,7 @@ def test_masked_reset_and_episode_streams():
     b = float(_basal(np.array([10]))[0])
     for _ in range(20):
         e.step(torch.full((n,), 3 * b, dtype=torch.float64, device=e.device))
-    snap = {k: getattr(e, k).clone() for k in ("x", "t", "cgm", "last_cgm", "prev_cgm", "episode", "pts", "ar_e")}
+    snap = {k: getattr(e, k).clone() for k in ("x", "t", "cgm", "cgm0", "last_cgm", "prev_risk", "episode", "pts", "ar_e")}
     mask = torch.zeros(n, dtype=torch.uint8); mask[::2] = 1
     o1 = e.reset(mask=mask).clone()
     odd, even = slice(1, None, 2), slice(0, None, 2)
@@ -164,7 +164,7 @@ def test_rollout_pid_matches_step_by_step_and_oracle(golden):
              "n_high": torch.zeros(n, dtype=torch.int32, device=eb.device)}
     for chunk in (1, 7, 100, 372):
         st = eb.rollout_pid(chunk, P, I, D, target, pid_state=st, stats=stats)
-    for k in ("x", "t", "cgm", "bg", "last_cgm", "prev_cgm", "reward", "planned"):
+    for k in ("x", "t", "cgm", "bg", "last_cgm", "prev_risk", "reward", "planned"):
         assert torch.allclose(getattr(ea, k).double(), getattr(eb, k).double(), rtol=0, atol=1e-9), k
     assert torch.allclose(st["integ"], integ, atol=1e-6) and torch.allclose(st["prev"], prev, atol=1e-9)
     assert abs(float(stats["min_bg"][0]) - min_bg) < 1e-9 and abs(float(stats["max_bg"][0]) - max_bg) < 1e-9
@@ -220,7 +220,7 @@ def test_rollout_bb_config1_matches_reference_host_loop_and_oracle(golden):
     tr = eb.new_trace(K)
     for chunk in (1, 9, 170, 300):
         stt = eb.rollout_bb(chunk, bb_state=stt, stats=stats, trace=tr)
-    for k in ("x", "t", "cgm", "bg", "last_cgm", "prev_cgm", "reward", "planned", "meal", "insulin"):
+    for k in ("x", "t", "cgm", "bg", "last_cgm", "prev_risk", "reward", "planned", "meal", "insulin"):
         assert torch.allclose(getattr(ea, k).double(), getattr(eb, k).double(), rtol=0, atol=1e-9), k
     assert torch.allclose(stt["prev_meal"], meal, atol=1e-12)
     assert np.array_equal(stats["n_high"].cpu().numpy(), (bg_a > 180).sum(0))

@@ -71,7 +71,7 @@ def test_env_step_vs_oracle_and_golden(golden, sensor, seed, pname, variant):
     r0 = orc.reset()
     assert abs(obs0[0] - r0["cgm"][0]) < 1e-10
     assert abs(obs0[0] - float(g["reset_cgm_" + tag])) < 1e-9
-    assert abs(env.prev_cgm.cpu().numpy()[0] - float(g["hist0_cgm_" + tag])) < 1e-9
+    assert abs(env.cgm0.cpu().numpy()[0] - float(g["hist0_cgm_" + tag])) < 1e-9
 
     keys = ("cgm", "bg", "reward", "lbgi", "hbgi", "risk", "meal", "insulin")
     worst_o = dict.fromkeys(keys, 0.0)
