@@ -332,11 +332,12 @@ __device__ __forceinline__ T measure_apply(const KArgs<T>& a, Env<T>& e, T gsub,
 // scenario.get_action(time) from the per-env meal table (scenario.py:33-42 / scenario_gen.py:23-31).
 // With the `next_meal` state array the common minute costs no table access at all: the minute of the
 // next entry travels with the env state and the table is touched only when a meal fires.
-template <typename T>
+// HAS_NEXT: the caller knows that the next_meal array exists (packed layout)
+template <typename T, bool HAS_NEXT = false>
 __device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& e)
 {
     T meal = T(0);
-    if (a.next_meal) {
+    if (HAS_NEXT || a.next_meal) {
         if (e.next_meal <= e.t) {                       // rare: a meal fires (or stale entries are skipped)
             while (e.cursor < a.n_meals) {
                 const int mt = at(rowv(a.meal_time, a.n, e.cursor), i);
@@ -345,6 +346,9 @@ __device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& 
                 ++e.cursor;
             }
             if (e.cursor >= a.n_meals) e.next_meal = INT_MAX;
+            // the table value is waited for inside this rare branch: at the join the wait would also cover, in every
+            // minute of every wave, whatever else is in flight (the previous chunk's stores, the next chunk's loads)
+            asm volatile("" : "+v"(meal));
         }
     } else if (e.cursor < a.n_meals) {
         int mt = at(rowv(a.meal_time, a.n, e.cursor), i);
@@ -505,9 +509,6 @@ constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a C
 #ifndef T1D_S1D_WAVES
 #define T1D_S1D_WAVES 3
 #endif
-#ifndef T1D_S1D_PREFETCH
-#define T1D_S1D_PREFETCH 0
-#endif
 constexpr int kS1DThreads = 256 * T1D_S1D_WAVES;      // step1d_kernel
 // EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
 // third risk evaluation drop out of the kernel altogether
@@ -576,7 +577,13 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         if (a.bolus) q_bolus = pump_quantise(bolus, lc[3], lc[4], lc[5]);                      // env.py:52
     }
     const T insulin = q_basal + q_bolus;
-    const T meal = a.cho ? at(a.cho, i) : meal_lookup(a, i, e);                               // env.py:50
+    T meal;                                                                                    // env.py:50
+    if (a.cho) {
+        meal = at(a.cho, i);
+        asm volatile("" : "+v"(meal));               // waited for on this path only (see meal_lookup)
+    } else {
+        meal = meal_lookup<T, true>(a, i, e);
+    }
     ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
     MinuteIn<T> u = eat_minute<1, T>(pl, e.x, meal, insulin, e.planned, e.lq, e.lf, e.eating);
     T f1 = T(0);
@@ -603,7 +610,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     }
     S1_MARK(2);
 #if T1D_S1_PHASE_PRIO
-    __builtin_amdgcn_s_setprio(0);                   // the integration fills the issue slots the other phases leave
+    if (MODE != 3) __builtin_amdgcn_s_setprio(0);    // the integration fills the issue slots the other phases leave
 #endif
     if (!ab_flag(a, 0x800)) {
         PropLdsS<T, STRIDE> pr{lpr, (int)pid};
@@ -788,25 +795,6 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
         };
     };
     int it = 0;
-#if T1D_S1D_PREFETCH
-    // the loads of a wave's next chunk are issued before the integration of the current one
-    {
-        int c = draw(&queue);
-        unsigned i = (unsigned)(first + c) * 64u + lane;
-        S1In<T> cur;
-        if (c < count && (int64_t)i < a.n) cur = s1_load(a, i);
-        while (c < count) {
-            const int c2 = draw(&queue);
-            const unsigned i2 = (unsigned)(first + c2) * 64u + lane;
-            __builtin_assume(i < (1u << 28));
-            __builtin_assume(i2 < (1u << 28));
-            S1In<T> nxt;
-            if (c2 < count && (int64_t)i2 < a.n) nxt = s1_load(a, i2);
-            if ((int64_t)i < a.n) s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, cur, on_level(i), tr, it);
-            cur = nxt; c = c2; i = i2; ++it;
-        }
-    }
-#else
     for (;; ++it) {
         const int c = draw(&queue);
         if (c >= count) break;                              // wave-uniform
@@ -819,7 +807,6 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
             s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, s1_load(a, i), on_level(i), tr, it);
         }
     }
-#endif
     tr = nullptr;
     S1D_PHASE(1);
     // every chunk of this CU has been drawn; those still in flight may yet add to the list
