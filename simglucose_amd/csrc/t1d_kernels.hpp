@@ -733,9 +733,9 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
         if (c >= count) break;                              // wave-uniform
         const unsigned i = (unsigned)(first + c) * 64u + lane;
         __builtin_assume(i < (1u << 28));
-        if ((int64_t)i >= a.n) continue;
         ++tk;
-        s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), tr, tk);
+        // (no `continue` for the lanes beyond the batch: they have to stay with their wave for the next draw)
+        if ((int64_t)i < a.n) s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), tr, tk);
     }
 }
 
@@ -750,7 +750,10 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
 // in-place form, lane for lane.
 // (Built, measured and not kept in round 2 -- git history, DESIGN.md: a third, coarser level for calm minutes with two
 // lists -- the launch is bound by HBM, not arithmetic, and every listed env costs ~25 scattered 64-byte fetches -- and
-// the level of an env's NEXT minute left in `meta` by the previous launch, so that the lists exist at launch start.)
+// the level of an env's NEXT minute left in `meta` by the previous launch, so that the lists exist at launch start;
+// the last eighth of the chunks in a pool any CU draws from through counters in device memory once its own run is done
+// (one counter: the draws serialise, +30 us; one per XCD: no faster than without); two waves per SIMD with the next
+// chunk's loads issued ahead of the integration: 88 us against 83.)
 // DREG: the list pass too takes its parameters from VGPRs: it ends the launch alone on its SIMDs, where LDS round trips
 // in the dependent chains count.
 template <typename T, bool EXTRA, bool DREG = false>
