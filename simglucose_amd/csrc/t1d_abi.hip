@@ -41,6 +41,8 @@ struct t1d_ctx {
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
     int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of level 2 aside from this many chunks per CU up
     int dreg_max_chunks = 65535;     // ... and run the list passes with VGPR parameters below this many chunks per CU
+    int minute_launches = 1;         // steps of several minutes as one single-minute launch per minute: 0 never, 1 from minute_launches_min_envs envs up, 2 always
+    int minute_launches_min_envs = 262144;
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
 };
@@ -337,6 +339,8 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         {"split_refill", &t1d_ctx::split_refill, 0, 1},
         {"defer_min_chunks", &t1d_ctx::defer_min_chunks, 0, 65535},
         {"dreg_max_chunks", &t1d_ctx::dreg_max_chunks, 0, 65535},
+        {"minute_launches", &t1d_ctx::minute_launches, 0, 2},
+        {"minute_launches_min_envs", &t1d_ctx::minute_launches_min_envs, 0, 1 << 28},
         {"s1_blocks", &t1d_ctx::s1_blocks, 0, 65535},
         {"adaptive_gut", &t1d_ctx::adaptive_gut, 0, 3},
         {"single_minute_kernel", &t1d_ctx::single_minute_kernel, 0, 1},
@@ -412,9 +416,19 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.pump.min_bolus = (T)c->pump[0]; a.pump.max_bolus = (T)c->pump[1]; a.pump.inc_bolus = (T)c->pump[2];
     a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
     a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
-    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags;
+    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags; a.sub = 0;
     a.prop = sizeof(T) == 8 ? (const T*)c->d_prop64 : (const T*)c->d_prop32;
     a.prop_rows = c->split_nsub ? kPropRows(c->split_nsub) : 0; a.np_pad = c->np_pad;
+    return a;
+}
+
+// minute `sub` of a `minutes`-minute step taken as one single-minute launch per minute
+template <typename T>
+static KArgs<T> make_args_sub(const t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, int sub)
+{
+    KArgs<T> a = make_args<T>(c, b, minutes, n_sub);
+    a.sub = sub;
+    if (a.cho) a.cho += (size_t)sub * (size_t)b->n;
     return a;
 }
 
@@ -488,7 +502,10 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
         else hipLaunchKernelGGL(refill_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
     }
     // one simulated minute per launch with the split integrator: the persistent early-store kernels
-    if (split_refill && split && minutes == 1 && c->single_minute_kernel && packed && !(T1D_AB_FLAGS && (b->flags & 0x600))) {
+    // (a step of several minutes of a large batch too: there the set-aside form of the step-size rule, one launch per
+    // minute, beats the in-place form of step_kernel, whose waves run at the level of their most refined lane)
+    const bool by_minute = minutes == 1 || c->minute_launches == 2 || (c->minute_launches == 1 && b->n >= c->minute_launches_min_envs);
+    if (split_refill && split && by_minute && c->single_minute_kernel && packed && !(T1D_AB_FLAGS && (b->flags & 0x600))) {
         const int stride = c->np <= 32 ? 32 : 64;
         const size_t dyn1 = (size_t)(DP_COUNT + kPropRows(n_sub)) * stride * esz;
         if (dyn1 + 512 <= (size_t)c->lds_per_block) {
@@ -505,20 +522,22 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
                                stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
-        hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+        hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
 #define T1D_LAUNCH_S1D(TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR>, dyn1d)); \
-        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR>), dim3(blocks), dim3(kS1DThreads), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR>), dim3(blocks), dim3(kS1DThreads), dyn1d, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
 #define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \
                                else { if (extra) T1D_LAUNCH_S1(TT, ST, true, false); else T1D_LAUNCH_S1(TT, ST, false, false); } } while (0)
 #define T1D_S1D_BY(TT) do { const bool dreg = per_block < c->dreg_max_chunks; \
                             if (extra) { if (dreg) T1D_LAUNCH_S1D(TT, true, true); else T1D_LAUNCH_S1D(TT, true, false); } \
                             else { if (dreg) T1D_LAUNCH_S1D(TT, false, true); else T1D_LAUNCH_S1D(TT, false, false); } } while (0)
-            if (defer) {
-                if (b->dtype == T1D_F64) T1D_S1D_BY(double); else T1D_S1D_BY(float);
-            } else if (b->dtype == T1D_F64) {
-                if (stride == 32) T1D_S1_BY(double, 32); else T1D_S1_BY(double, 64);
-            } else {
-                if (stride == 32) T1D_S1_BY(float, 32); else T1D_S1_BY(float, 64);
+            for (int sub = 0; sub < minutes; ++sub) {
+                if (defer) {
+                    if (b->dtype == T1D_F64) T1D_S1D_BY(double); else T1D_S1D_BY(float);
+                } else if (b->dtype == T1D_F64) {
+                    if (stride == 32) T1D_S1_BY(double, 32); else T1D_S1_BY(double, 64);
+                } else {
+                    if (stride == 32) T1D_S1_BY(float, 32); else T1D_S1_BY(float, 64);
+                }
             }
 #undef T1D_S1D_BY
 #undef T1D_S1_BY

@@ -53,6 +53,7 @@ template <typename T> struct KArgs {
     long long* trace;       // T1D_S1_TRACE builds only: phase timestamps of the first blocks' waves
     SensorC<T> sen; PumpC<T> pump;
     int np, S, n_meals, n_normals, minutes, n_sub, flags, prop_rows, np_pad;
+    int sub;                // single-minute kernels: which minute of a `minutes`-minute step this launch is (0 .. minutes - 1)
 };
 
 template <typename T> struct PidArgs {
@@ -604,9 +605,19 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
         if (meta1 != meta) at(I(1), i) = (int32_t)meta1;
     }
+    // A step of several minutes (sample_time > 1) as one launch per minute: the outputs are the means over the step's
+    // minutes (env.py:78-81), summed up in the output arrays in the order step_kernel sums them in registers; reward,
+    // done and the risk indices follow in the step's last minute.
+    const bool sub_first = a.sub == 0, sub_last = a.sub == a.minutes - 1;
+    const T inv_div = T(1) / T(a.minutes);
     if (EXTRA) {
-        if (a.meal) at(a.meal, i) = meal;
-        if (a.insulin) at(a.insulin, i) = insulin;
+        if (a.minutes == 1) {
+            if (a.meal) at(a.meal, i) = meal;
+            if (a.insulin) at(a.insulin, i) = insulin;
+        } else {
+            if (a.meal) at(a.meal, i) = (sub_first ? T(0) : (T)at(a.meal, i)) + meal * inv_div;
+            if (a.insulin) at(a.insulin, i) = (sub_first ? T(0) : (T)at(a.insulin, i)) + insulin * inv_div;
+        }
     }
     S1_MARK(2);
 #if T1D_S1_PHASE_PRIO
@@ -639,7 +650,9 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     for (int k = 0; k < 4; ++k) e.cur[k] = at(X(40 + k), i);
     // with a 1-minute sensor every minute takes a fresh sample: the held value is never read
     T last_cgm = a.sen.st == 1 ? T(0) : (T)at(X(16), i);
-    const T rp = at(X(17), i);                                // risk index of the previous step's CGM
+    const T rp = sub_last ? (T)at(X(17), i) : T(0);           // risk index of the previous step's CGM
+    T bg_sum = T(0), cgm_sum = T(0);
+    if (!sub_first) { bg_sum = at(a.bg, i); cgm_sum = at(a.cgm, i); }
     S1_MARK(4);
     bool due, entered = false;
     const T noise = measure_noise<false>(a, i, e, due, &entered);       // e.t is still the minute's start: sample for t + 1
@@ -658,19 +671,24 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         last_cgm = c;
         if (a.sen.st != 1) at(X(16), i) = c;                  // the zero-order hold is dead state with a 1-minute sensor
     }
+    T cgm_out = last_cgm, bg_out = gsub;
+    if (a.minutes != 1) {                                                                      // env.py:78-81
+        cgm_out = cgm_sum + last_cgm * inv_div; bg_out = bg_sum + gsub * inv_div;
+    }
+    at(a.cgm, i) = cgm_out; at(a.bg, i) = bg_out;
+    if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+    if (!sub_last) return;
     T l, h, r, rc = T(0);
-    if (!ab_flag(a, 0x100)) risk_index1<1>(last_cgm, l, h, rc);
+    if (!ab_flag(a, 0x100)) risk_index1<1>(cgm_out, l, h, rc);
     at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
     at(X(17), i) = rc;
-    at(a.cgm, i) = last_cgm; at(a.bg, i) = gsub;
-    at(a.done, i) = (gsub < T(70) || gsub > T(350)) ? 1 : 0;                                   // env.py:103
+    at(a.done, i) = (bg_out < T(70) || bg_out > T(350)) ? 1 : 0;                               // env.py:103
     if (EXTRA && (a.lbgi || a.hbgi || a.risk)) {
-        risk_index1<1>(gsub, l, h, r);                                                         // env.py:85
+        risk_index1<1>(bg_out, l, h, r);                                                       // env.py:85
         if (a.lbgi) at(a.lbgi, i) = l;
         if (a.hbgi) at(a.hbgi, i) = h;
         if (a.risk) at(a.risk, i) = r;
     }
-    if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
 #if T1D_S1_TRACE
     if (tr && (threadIdx.x & 63) == 0 && tk < 6) tr[tk * 8 + 5] = (long long)wall_clock64();    // epilogue computed, stores issued
 #endif

@@ -696,3 +696,38 @@ def test_full_size_24h_run_sampled_envs_match_oracle(adaptive):
         assert (worst_env <= 1e-3).mean() > 0.85 and np.median(worst_env) < 4e-4, ((worst_env <= 1e-3).mean(), np.median(worst_env))
     assert np.abs(e.x[:, sidx].cpu().numpy() - orc.x).max() < 1e-6
     assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K == int(e.t.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor,dtype_name", [("Dexcom", "f64"), ("GuardianRT", "f64"), ("Dexcom", "f32")])
+def test_multi_minute_step_as_one_launch_per_minute(sensor, dtype_name):
+    """A step of sample_time minutes taken as one single-minute launch per minute (what large batches do: the set-aside
+    form of the step-size rule) against the same step inside one launch of the generic kernel: same lanes refine, same
+    arithmetic, outputs summed in the same order -- meals from tables, extra outputs, 8 h."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    dt = torch.float64 if dtype_name == "f64" else torch.float32
+    n = 64 * 50 - 5
+    pid = np.arange(n) % 30
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=7 * 60, seed=3, device="cuda:0", dtype=dt)
+    envs = []
+    for mode in (0, 2):
+        e = _mk(patient=pid, sensor=sensor, dtype=dt, noise="philox", seed=9, n_sub=4, extra_outputs=True)
+        e.set_option("minute_launches", mode)
+        e.set_meals(mt, ma)
+        e.reset()
+        envs.append(e)
+    b = torch.as_tensor(_basal(pid), device="cuda:0", dtype=dt)
+    tol = 1e-9 if dtype_name == "f64" else 2e-3
+    steps = 480 // int(envs[0].sample_time)
+    for k in range(steps):
+        a = b * (0.4 + 0.3 * (k % 5))
+        o0 = envs[0].step(a); o1 = envs[1].step(a)
+        if k % 20 == 19 or k == 0:
+            for key in ("cgm", "bg", "reward", "risk", "lbgi", "hbgi", "meal", "insulin"):
+                assert float((getattr(envs[0], key) - getattr(envs[1], key)).abs().max()) < tol, (k, key)
+            assert torch.equal(envs[0].done, envs[1].done)
+    assert torch.equal(envs[0].t, envs[1].t) and int(envs[0].t[0]) == steps * int(envs[0].sample_time)
+    assert float((envs[0].x - envs[1].x).abs().max()) < tol * 100
+    assert float((envs[0].prev_risk - envs[1].prev_risk).abs().max()) < tol
+    assert envs[0].sync() == 0 and envs[1].sync() == 0
