@@ -179,7 +179,8 @@ __device__ __forceinline__ double fdiv(double a, double b)
     const double q = a * y;
     return fma(fma(-b, q, a), y, q);
 }
-__device__ __forceinline__ float fdiv(float a, float b) { return __fdividef(a, b); }
+// (fp32: v_rcp_f32, 1 ulp, and the product -- __fdividef compiles to the IEEE scale / fmas / fixup sequence, ten instructions)
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 // a / b to ~3e-15 relative: the seed, one Newton step, the product; no residual correction (3 instructions less).
 // For the quotients inside the sub-step loops (gastric emptying, insulin-dependent utilisation).
 __device__ __forceinline__ double fdiv_loop(double a, double b)
@@ -188,7 +189,7 @@ __device__ __forceinline__ double fdiv_loop(double a, double b)
     y = fma(y, fma(-b, y, 1.0), y);
     return a * y;
 }
-__device__ __forceinline__ float fdiv_loop(float a, float b) { return __fdividef(a, b); }
+__device__ __forceinline__ float fdiv_loop(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 // log(v) for finite v > 0 (fdlibm-style: v = 2^e m, m in [sqrt(1/2), sqrt 2), s = f/(2+f),
 // degree-7 even polynomial in s^2); ~35 VALU ops, < 1 ulp.

@@ -609,7 +609,8 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     // minutes (env.py:78-81), summed up in the output arrays in the order step_kernel sums them in registers; reward,
     // done and the risk indices follow in the step's last minute.
     const bool sub_first = a.sub == 0, sub_last = a.sub == a.minutes - 1;
-    const T inv_div = T(1) / T(a.minutes);
+    T inv_div = T(1);
+    if (a.minutes != 1) inv_div = T(1) / T(a.minutes);       // (a division: not on the one-minute path)
     if (EXTRA) {
         if (a.minutes == 1) {
             if (a.meal) at(a.meal, i) = meal;
