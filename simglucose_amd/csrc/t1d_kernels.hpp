@@ -510,7 +510,12 @@ constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a C
 #ifndef T1D_S1D_WAVES
 #define T1D_S1D_WAVES 3
 #endif
-constexpr int kS1DThreads = 256 * T1D_S1D_WAVES;      // step1d_kernel
+#ifndef T1D_S1D_WAVES_F32
+#define T1D_S1D_WAVES_F32 4
+#endif
+// step1d_kernel: three waves per SIMD in fp64 (<= 168 VGPRs); the fp32 instantiation fits four (<= 128: 45.8 against 48.3 us
+// at 1 Mi envs -- there the vector pipe and the memory floor are level, and the fourth wave buys overlap)
+template <typename T> constexpr int s1d_threads() { return 256 * (sizeof(T) == 4 ? T1D_S1D_WAVES_F32 : T1D_S1D_WAVES); }
 // EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
 // third risk evaluation drop out of the kernel altogether
 //
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
 // DREG: the list pass too takes its parameters from VGPRs: it ends the launch alone on its SIMDs, where LDS round trips
 // in the dependent chains count.
 template <typename T, bool EXTRA, bool DREG = false>
-__global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a, int nchunks)
+__global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
     constexpr int STRIDE = 32;
     T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(kS1DThreads, 1) void step1d_kernel(const KArgs<T> a
     long long* tr = nullptr;
 #if T1D_S1_TRACE
     // tuning builds: wall clock (100 MHz) of every wave of the first 32 workgroups at the phase boundaries of the launch
-    long long* const ph = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (kS1DThreads / 64) + threadIdx.x / 64) * 64 : nullptr;
+    long long* const ph = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (s1d_threads<T>() / 64) + threadIdx.x / 64) * 64 : nullptr;
 #define S1D_PHASE(k) do { if (ph && lane == 0) ph[k] = (long long)wall_clock64(); } while (0)
 #else
 #define S1D_PHASE(k) do { } while (0)

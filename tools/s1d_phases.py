@@ -24,7 +24,7 @@ out = np.zeros(128 * 4 * 64, dtype=np.int64)
 L = _lib.lib()
 L.t1d_debug_trace.argtypes = [C.c_void_p, C.c_void_p]
 assert L.t1d_debug_trace(env._ctx, out.ctypes.data_as(C.c_void_p)) == 0
-nw = int(os.environ.get('T1D_S1_WAVES', '3')) * 4
+nw = int(os.environ.get('T1D_S1_WAVES', '4' if dt == torch.float32 else '3')) * 4
 tr = out[:32 * nw * 64].reshape(32, nw, 64)
 t = tr[:, :, :5].astype(np.float64) * 0.01                    # us (100 MHz)
 t0 = t[:, :, 0].min()
