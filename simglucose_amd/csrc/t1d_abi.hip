@@ -522,7 +522,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
                                stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
-        hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(kS1Threads), dyn1, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
+        hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(s1_threads<TT>()), dyn1, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
 #define T1D_LAUNCH_S1D(TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR>, dyn1d)); \
         hipLaunchKernelGGL((step1d_kernel<TT, EX, DR>), dim3(blocks), dim3(s1d_threads<TT>()), dyn1d, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
 #define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \

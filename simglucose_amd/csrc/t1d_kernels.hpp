@@ -506,7 +506,8 @@ __global__ __launch_bounds__(kBlock, T1D_WAVES) void step_kernel(const KArgs<T> 
 #else
 #define S1_MARK(m) do { } while (0)
 #endif
-constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a CU: T1D_S1_WAVES waves on each of its 4 SIMDs
+// one workgroup fills a CU: T1D_S1_WAVES waves on each of its 4 SIMDs in fp64, T1D_S1D_WAVES_F32 in fp32 (see s1d_threads)
+template <typename T> constexpr int s1_threads();
 #ifndef T1D_S1D_WAVES
 #define T1D_S1D_WAVES 3
 #endif
@@ -516,6 +517,7 @@ constexpr int kS1Threads = 256 * T1D_S1_WAVES;        // one workgroup fills a C
 // step1d_kernel: three waves per SIMD in fp64 (<= 168 VGPRs); the fp32 instantiation fits four (<= 128: 45.8 against 48.3 us
 // at 1 Mi envs -- there the vector pipe and the memory floor are level, and the fourth wave buys overlap)
 template <typename T> constexpr int s1d_threads() { return 256 * (sizeof(T) == 4 ? T1D_S1D_WAVES_F32 : T1D_S1D_WAVES); }
+template <typename T> constexpr int s1_threads() { return 256 * (sizeof(T) == 4 ? T1D_S1D_WAVES_F32 : T1D_S1_WAVES); }
 // EXTRA: the optional outputs (lbgi, hbgi, risk, meal, insulin) exist; without them their five pointers and the
 // third risk evaluation drop out of the kernel altogether
 //
@@ -724,7 +726,7 @@ __device__ __forceinline__ void s1_stage_tables(const KArgs<T>& a, T* ldp, T* lp
 
 // every lane in place: TIERED = step sizes by the rule (LDS parameters), else level 1 everywhere (VGPR parameters)
 template <typename T, int STRIDE, bool EXTRA, bool TIERED>
-__global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, int nchunks)
+__global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
     // prev_risk and the 26 noise rows; rows 1, 2 of the t buffer are meta and next_meal.  Deriving them from two
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(kS1Threads, 1) void step1_kernel(const KArgs<T> a, 
     const int count = nchunks - first < per_block ? nchunks - first : per_block;
     const unsigned lane = threadIdx.x & 63u;
 #if T1D_S1_TRACE
-    long long* tr = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (kS1Threads / 64) + threadIdx.x / 64) * 64 : nullptr;
+    long long* tr = (a.trace && blockIdx.x < 32) ? a.trace + (blockIdx.x * (s1_threads<T>() / 64) + threadIdx.x / 64) * 64 : nullptr;
 #else
     long long* tr = nullptr;
 #endif

@@ -5,7 +5,7 @@ import collections, os, re, subprocess, sys, tempfile
 pat = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tmp = tempfile.mkdtemp()
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-save-temps"] + sys.argv[2:] +
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-save-temps"] + sys.argv[2:] +
                       ["-o", os.path.join(tmp, "lib.so"), os.path.join(root, "simglucose_amd", "csrc", "t1d_abi.hip")], cwd=tmp, stderr=subprocess.DEVNULL)
 s = open(os.path.join(tmp, "t1d_abi-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 for m in re.finditer(r"^(_Z\w+):\s*; @", s, re.M):
