@@ -523,14 +523,16 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
                                stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
         hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(s1_threads<TT>()), dyn1, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
-#define T1D_LAUNCH_S1D(TT, EX, DR) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR>, dyn1d)); \
-        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR>), dim3(blocks), dim3(s1d_threads<TT>()), dyn1d, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
+#define T1D_LAUNCH_S1D_M(TT, EX, DR, MU) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR, MU>, dyn1d)); \
+        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR, MU>), dim3(blocks), dim3(s1d_threads<TT>()), dyn1d, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
+#define T1D_LAUNCH_S1D(TT, EX, DR) do { if (minutes == 1) T1D_LAUNCH_S1D_M(TT, EX, DR, false); else T1D_LAUNCH_S1D_M(TT, EX, DR, true); } while (0)
 #define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \
                                else { if (extra) T1D_LAUNCH_S1(TT, ST, true, false); else T1D_LAUNCH_S1(TT, ST, false, false); } } while (0)
 #define T1D_S1D_BY(TT) do { const bool dreg = per_block < c->dreg_max_chunks; \
                             if (extra) { if (dreg) T1D_LAUNCH_S1D(TT, true, true); else T1D_LAUNCH_S1D(TT, true, false); } \
                             else { if (dreg) T1D_LAUNCH_S1D(TT, false, true); else T1D_LAUNCH_S1D(TT, false, false); } } while (0)
-            for (int sub = 0; sub < minutes; ++sub) {
+            // (steps of several minutes: only in the set-aside form -- otherwise the generic kernel below takes them)
+            for (int sub = 0; sub < (minutes == 1 || defer ? minutes : 0); ++sub) {
                 if (defer) {
                     if (b->dtype == T1D_F64) T1D_S1D_BY(double); else T1D_S1D_BY(float);
                 } else if (b->dtype == T1D_F64) {
@@ -542,9 +544,12 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
 #undef T1D_S1D_BY
 #undef T1D_S1_BY
 #undef T1D_LAUNCH_S1D
+#undef T1D_LAUNCH_S1D_M
 #undef T1D_LAUNCH_S1
-            T1D_HIP(hipGetLastError());
-            return T1D_OK;
+            if (minutes == 1 || defer) {
+                T1D_HIP(hipGetLastError());
+                return T1D_OK;
+            }
         }
     }
 #define T1D_LAUNCH_STEP(V, TT, RF) hipLaunchKernelGGL((step_kernel<V, TT, RF>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))

@@ -549,7 +549,8 @@ __device__ __forceinline__ S1In<T> s1_load(const KArgs<T>& a, unsigned i)
     return in;
 }
 
-template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONLEVEL>
+// MULTI: the launch is one minute of a step of several (t1d_step's minute_launches); otherwise a.minutes == 1, a.sub == 0
+template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, bool MULTI, typename ONLEVEL>
 __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, const S1In<T>& in,
                                          ONLEVEL&& on_level, long long* tr, int tk)
 {
@@ -615,11 +616,10 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     // A step of several minutes (sample_time > 1) as one launch per minute: the outputs are the means over the step's
     // minutes (env.py:78-81), summed up in the output arrays in the order step_kernel sums them in registers; reward,
     // done and the risk indices follow in the step's last minute.
-    const bool sub_first = a.sub == 0, sub_last = a.sub == a.minutes - 1;
-    T inv_div = T(1);
-    if (a.minutes != 1) inv_div = T(1) / T(a.minutes);       // (a division: not on the one-minute path)
+    const bool sub_first = !MULTI || a.sub == 0, sub_last = !MULTI || a.sub == a.minutes - 1;
+    const T inv_div = MULTI ? T(1) / T(a.minutes) : T(1);
     if (EXTRA) {
-        if (a.minutes == 1) {
+        if (!MULTI) {
             if (a.meal) at(a.meal, i) = meal;
             if (a.insulin) at(a.insulin, i) = insulin;
         } else {
@@ -680,7 +680,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         if (a.sen.st != 1) at(X(16), i) = c;                  // the zero-order hold is dead state with a 1-minute sensor
     }
     T cgm_out = last_cgm, bg_out = gsub;
-    if (a.minutes != 1) {                                                                      // env.py:78-81
+    if (MULTI) {                                                                               // env.py:78-81
         cgm_out = cgm_sum + last_cgm * inv_div; bg_out = bg_sum + gsub * inv_div;
     }
     at(a.cgm, i) = cgm_out; at(a.bg, i) = bg_out;
@@ -725,7 +725,7 @@ __device__ __forceinline__ void s1_stage_tables(const KArgs<T>& a, T* ldp, T* lp
 }
 
 // every lane in place: TIERED = step sizes by the rule (LDS parameters), else level 1 everywhere (VGPR parameters)
-template <typename T, int STRIDE, bool EXTRA, bool TIERED>
+template <typename T, int STRIDE, bool EXTRA, bool TIERED, bool MULTI = false>
 __global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T
         __builtin_assume(i < (1u << 28));
         ++tk;
         // (no `continue` for the lanes beyond the batch: they have to stay with their wave for the next draw)
-        if ((int64_t)i < a.n) s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), tr, tk);
+        if ((int64_t)i < a.n) s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0, MULTI>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), tr, tk);
     }
 }
 
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T
 // chunk's loads issued ahead of the integration: 88 us against 83.)
 // DREG: the list pass too takes its parameters from VGPRs: it ends the launch alone on its SIMDs, where LDS round trips
 // in the dependent chains count.
-template <typename T, bool EXTRA, bool DREG = false>
+template <typename T, bool EXTRA, bool DREG = false, bool MULTI = false>
 __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
     constexpr int STRIDE = 32;
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
 #if T1D_S1_TRACE
             tr = ph ? ph + 16 : nullptr;                    // per-chunk phase marks of the wave's first six chunks
 #endif
-            s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, s1_load(a, i), on_level(i), tr, it);
+            s1_chunk<true, T, STRIDE, EXTRA, 2, MULTI>(a, ldp, lpr, lconst, i, s1_load(a, i), on_level(i), tr, it);
         }
     }
     tr = nullptr;
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
         if (lo + (int)lane < total) {
             const unsigned i = base + (unsigned)list[lo + (int)lane];
             __builtin_assume(i < (1u << 28));
-            s1_chunk<DREG, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), nullptr, 0);
+            s1_chunk<DREG, T, STRIDE, EXTRA, 3, MULTI>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), nullptr, 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
