@@ -518,7 +518,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
             // (step1d_kernel) where the list of the CU's envs fits next to the tables; adaptive_gut = 2 asks for the
             // in-place form, 3 for the set-aside form at any batch size
             const int per_block = (nchunks + blocks - 1) / blocks;
-            const size_t dyn1d = dyn1 + (size_t)per_block * 64 * sizeof(uint16_t);
+            const size_t dyn1d = dyn1 + (size_t)kS1DPark * (18 * esz + 3 * sizeof(int)) + (size_t)per_block * 64 * sizeof(uint16_t);
             const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
                                stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \

@@ -550,6 +550,29 @@ __device__ __forceinline__ S1In<T> s1_load(const KArgs<T>& a, unsigned i)
 }
 
 // MULTI: the launch is one minute of a step of several (t1d_step's minute_launches); otherwise a.minutes == 1, a.sub == 0
+// What s1_load fetched, kept in LDS for the listed envs (step1d_kernel): pt = [18][kS1DPark] of T, pi = [3][kS1DPark] ints
+constexpr int kS1DPark = 128;                                  // listed envs per CU whose inputs wait in LDS (a multiple of 64)
+template <typename T>
+__device__ __forceinline__ void s1_park(const S1In<T>& in, T* pt, int* pi, int slot)
+{
+#pragma unroll
+    for (int k = 0; k < 13; ++k) pt[k * kS1DPark + slot] = in.x[k];
+    pt[13 * kS1DPark + slot] = in.planned; pt[14 * kS1DPark + slot] = in.lq; pt[15 * kS1DPark + slot] = in.lf;
+    pt[16 * kS1DPark + slot] = in.basal; pt[17 * kS1DPark + slot] = in.bolus;
+    pi[slot] = (int)in.meta; pi[kS1DPark + slot] = in.t; pi[2 * kS1DPark + slot] = in.next_meal;
+}
+template <typename T>
+__device__ __forceinline__ S1In<T> s1_unpark(const T* pt, const int* pi, int slot)
+{
+    S1In<T> in;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) in.x[k] = pt[k * kS1DPark + slot];
+    in.planned = pt[13 * kS1DPark + slot]; in.lq = pt[14 * kS1DPark + slot]; in.lf = pt[15 * kS1DPark + slot];
+    in.basal = pt[16 * kS1DPark + slot]; in.bolus = pt[17 * kS1DPark + slot];
+    in.meta = (uint32_t)pi[slot]; in.t = pi[kS1DPark + slot]; in.next_meal = pi[2 * kS1DPark + slot];
+    return in;
+}
+
 template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, bool MULTI, typename ONLEVEL>
 __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, const S1In<T>& in,
                                          ONLEVEL&& on_level, long long* tr, int tk)
@@ -790,8 +813,12 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
     T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
     const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
     const unsigned lane = threadIdx.x & 63u;
+    // what the main pass had loaded of the first kS1DPark listed envs: the pass over the list starts from LDS, not from a
+    // second, scattered fetch (which sits on the critical path of the CU's last wave)
+    T* const park_t = lpr + a.prop_rows * STRIDE;           // [18][kS1DPark]
+    int* const park_i = (int*)(park_t + 18 * kS1DPark);     // [3][kS1DPark]
     // [per_block * 64] envs of level 2, as offsets from the workgroup's first env (< 65536: t1d_step)
-    uint16_t* const list = (uint16_t*)(lpr + a.prop_rows * STRIDE);
+    uint16_t* const list = (uint16_t*)(park_i + 3 * kS1DPark);
     __shared__ int queue, taken, listed, passed;
     __shared__ T lconst[8];
     s1_stage_tables<T, STRIDE>(a, ldp, lpr, lconst);
@@ -814,9 +841,13 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
         if (lane == 0) g = atomicAdd(counter, 1);
         return __builtin_amdgcn_readfirstlane(g);
     };
-    auto on_level = [&](unsigned i) {
+    auto on_level = [&](unsigned i, const S1In<T>& in) {
         return [&, i](bool level2) {
-            if (level2) list[atomicAdd(&listed, 1)] = (uint16_t)(i - base);
+            if (level2) {
+                const int slot = atomicAdd(&listed, 1);
+                list[slot] = (uint16_t)(i - base);
+                if (slot < kS1DPark) s1_park(in, park_t, park_i, slot);
+            }
             // lane 0 of a chunk is always a live env: it reports the chunk past its decision point, after the
             // list entries of the wave (LDS operations of one wave execute in order)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -833,7 +864,8 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
 #if T1D_S1_TRACE
             tr = ph ? ph + 16 : nullptr;                    // per-chunk phase marks of the wave's first six chunks
 #endif
-            s1_chunk<true, T, STRIDE, EXTRA, 2, MULTI>(a, ldp, lpr, lconst, i, s1_load(a, i), on_level(i), tr, it);
+            const S1In<T> in = s1_load(a, i);
+            s1_chunk<true, T, STRIDE, EXTRA, 2, MULTI>(a, ldp, lpr, lconst, i, in, on_level(i, in), tr, it);
         }
     }
     tr = nullptr;
@@ -853,7 +885,9 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
         if (lo + (int)lane < total) {
             const unsigned i = base + (unsigned)list[lo + (int)lane];
             __builtin_assume(i < (1u << 28));
-            s1_chunk<DREG, T, STRIDE, EXTRA, 3, MULTI>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), nullptr, 0);
+            // (wave-uniform: a group of 64 entries lies inside the parked range or beyond it)
+            const S1In<T> in = lo + 64 <= kS1DPark ? s1_unpark<T>(park_t, park_i, lo + (int)lane) : s1_load(a, i);
+            s1_chunk<DREG, T, STRIDE, EXTRA, 3, MULTI>(a, ldp, lpr, lconst, i, in, S1NoLevel(), nullptr, 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
