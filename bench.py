@@ -200,7 +200,7 @@ def main(argv=None):
     ap.add_argument("--in-place", action="store_true",
                     help="every lane takes its step-size level in place (adaptive_gut = 2) instead of levels 1 and 2 being set aside")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
-                    help="t1d_ctx_set_option switches applied after the ones above (tuning runs), e.g. --opt dreg_max_chunks=0")
+                    help="t1d_ctx_set_option switches applied after the ones above (tuning runs), e.g. --opt minute_launches=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--accuracy-envs", type=int, default=256)
@@ -319,7 +319,7 @@ def main(argv=None):
         if integ != "rk4" and st == 1:
             kernel_name = {"split": "void t1d::step1_kernel<%s, 32, false, false, false>(t1d::KArgs<%s>, int)",
                            "split_adaptive": "void t1d::step1_kernel<%s, 32, false, true, false>(t1d::KArgs<%s>, int)" if a.in_place
-                                             else "void t1d::step1d_kernel<%s, false, true, false>(t1d::KArgs<%s>, int)"}[integ] % (tname, tname)
+                                             else "void t1d::step1d_kernel<%s, false, false>(t1d::KArgs<%s>, int)"}[integ] % (tname, tname)
         else:
             kernel_name = "void t1d::step_kernel<%d, %s, false>(t1d::KArgs<%s>)" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname, tname)
         # last recorded PMC measurements of this exact configuration (tools/profile_bench.sh): HBM bytes, VALU instructions

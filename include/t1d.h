@@ -229,8 +229,7 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  *   registers would otherwise cost the step kernel ~20 %); 0 = always inline.
  * "single_minute_kernel": 1 (default) = one-minute launches on the packed layout take the persistent kernels.
  * "s1_blocks": grid of those kernels (0 = one workgroup per compute unit).
- * "defer_min_chunks", "dreg_max_chunks": thresholds (64-env chunks per workgroup) from which the set-aside form is
- *   used, and below which its list pass keeps its parameters in vector registers.
+ * "defer_min_chunks": threshold (64-env chunks per workgroup) from which the set-aside form is used.
  * "minute_launches": a step of several minutes (1 < minutes <= sample_time) on the packed layout as one such launch per
  *   minute, the outputs summed up in the output arrays: 1 (default) = for batches of "minute_launches_min_envs" (262 144)
  *   envs or more, where the set-aside form beats the in-place form of the generic kernel (1 Mi envs fp64, Dexcom:

@@ -40,7 +40,6 @@ struct t1d_ctx {
     double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
     int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of level 2 aside from this many chunks per CU up
-    int dreg_max_chunks = 65535;     // ... and run the list passes with VGPR parameters below this many chunks per CU
     int minute_launches = 1;         // steps of several minutes as one single-minute launch per minute: 0 never, 1 from minute_launches_min_envs envs up, 2 always
     int minute_launches_min_envs = 262144;
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
@@ -338,7 +337,6 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         {"math", &t1d_ctx::math, 0, 1},
         {"split_refill", &t1d_ctx::split_refill, 0, 1},
         {"defer_min_chunks", &t1d_ctx::defer_min_chunks, 0, 65535},
-        {"dreg_max_chunks", &t1d_ctx::dreg_max_chunks, 0, 65535},
         {"minute_launches", &t1d_ctx::minute_launches, 0, 2},
         {"minute_launches_min_envs", &t1d_ctx::minute_launches_min_envs, 0, 1 << 28},
         {"s1_blocks", &t1d_ctx::s1_blocks, 0, 65535},
@@ -523,14 +521,12 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
                                stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
         hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(s1_threads<TT>()), dyn1, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
-#define T1D_LAUNCH_S1D_M(TT, EX, DR, MU) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, DR, MU>, dyn1d)); \
-        hipLaunchKernelGGL((step1d_kernel<TT, EX, DR, MU>), dim3(blocks), dim3(s1d_threads<TT>()), dyn1d, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
-#define T1D_LAUNCH_S1D(TT, EX, DR) do { if (minutes == 1) T1D_LAUNCH_S1D_M(TT, EX, DR, false); else T1D_LAUNCH_S1D_M(TT, EX, DR, true); } while (0)
+#define T1D_LAUNCH_S1D_M(TT, EX, MU) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, MU>, dyn1d)); \
+        hipLaunchKernelGGL((step1d_kernel<TT, EX, MU>), dim3(blocks), dim3(s1d_threads<TT>()), dyn1d, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
+#define T1D_LAUNCH_S1D(TT, EX) do { if (minutes == 1) T1D_LAUNCH_S1D_M(TT, EX, false); else T1D_LAUNCH_S1D_M(TT, EX, true); } while (0)
 #define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \
                                else { if (extra) T1D_LAUNCH_S1(TT, ST, true, false); else T1D_LAUNCH_S1(TT, ST, false, false); } } while (0)
-#define T1D_S1D_BY(TT) do { const bool dreg = per_block < c->dreg_max_chunks; \
-                            if (extra) { if (dreg) T1D_LAUNCH_S1D(TT, true, true); else T1D_LAUNCH_S1D(TT, true, false); } \
-                            else { if (dreg) T1D_LAUNCH_S1D(TT, false, true); else T1D_LAUNCH_S1D(TT, false, false); } } while (0)
+#define T1D_S1D_BY(TT) do { if (extra) T1D_LAUNCH_S1D(TT, true); else T1D_LAUNCH_S1D(TT, false); } while (0)
             // (steps of several minutes: only in the set-aside form -- otherwise the generic kernel below takes them)
             for (int sub = 0; sub < (minutes == 1 || defer ? minutes : 0); ++sub) {
                 if (defer) {

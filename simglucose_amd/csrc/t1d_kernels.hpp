@@ -803,9 +803,9 @@ __global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T
 // the last eighth of the chunks in a pool any CU draws from through counters in device memory once its own run is done
 // (one counter: the draws serialise, +30 us; one per XCD: no faster than without); two waves per SIMD with the next
 // chunk's loads issued ahead of the integration: 88 us against 83.)
-// DREG: the list pass too takes its parameters from VGPRs: it ends the launch alone on its SIMDs, where LDS round trips
-// in the dependent chains count.
-template <typename T, bool EXTRA, bool DREG = false, bool MULTI = false>
+// The list pass too takes its parameters from VGPRs: it ends the launch alone on its SIMDs, where LDS round trips in the
+// dependent chains count.
+template <typename T, bool EXTRA, bool MULTI = false>
 __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
     constexpr int STRIDE = 32;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
             __builtin_assume(i < (1u << 28));
             // (wave-uniform: a group of 64 entries lies inside the parked range or beyond it)
             const S1In<T> in = lo + 64 <= kS1DPark ? s1_unpark<T>(park_t, park_i, lo + (int)lane) : s1_load(a, i);
-            s1_chunk<DREG, T, STRIDE, EXTRA, 3, MULTI>(a, ldp, lpr, lconst, i, in, S1NoLevel(), nullptr, 0);
+            s1_chunk<true, T, STRIDE, EXTRA, 3, MULTI>(a, ldp, lpr, lconst, i, in, S1NoLevel(), nullptr, 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
