@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid (needs a -DT1D_S1_TRACE=1 build in T1D_LIB_PATH): when the waves of step1d_kernel's first 32 workgroups
-reach the phase boundaries of a launch -- main pass done, every chunk past its decision point, level-2 list done,
-level-1 list done -- and how long the lists were.   usage: s1d_phases.py [envs] [dtype f64|f32]"""
+reach the phase boundaries of a launch -- main pass done, every chunk past its decision point, list pass done -- and how
+long the lists were; then the per-chunk phase times of the main pass.   usage: s1d_phases.py [envs] [dtype f64|f32]"""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,24 +28,21 @@ nw = int(os.environ.get('T1D_S1_WAVES', '4' if dt == torch.float32 else '3')) * 
 tr = out[:32 * nw * 64].reshape(32, nw, 64)
 t = tr[:, :, :5].astype(np.float64) * 0.01                    # us (100 MHz)
 t0 = t[:, :, 0].min()
-names = ["start", "main pass done (wave)", "all chunks decided", "level-2 list done", "level-1 list done"]
-for k in range(5):
+names = ["start", "main pass done (wave)", "all chunks decided", "list pass done"]
+for k in range(4):
     v = t[:, :, k] - t0
     print("%-26s mean %7.2f  min %7.2f  max %7.2f us" % (names[k], v.mean(), v.min(), v.max()))
-print("%-26s mean %7.2f  min %7.2f  max %7.2f us" % ("kernel entry", (tr[:, :, 11] * 0.01 - t0).mean(), (tr[:, :, 11] * 0.01 - t0).min(), (tr[:, :, 11] * 0.01 - t0).max()))
-print("%-26s mean %7.2f  min %7.2f  max %7.2f us" % ("lists scanned (barrier)", (tr[:, :, 5] * 0.01 - t0).mean(), (tr[:, :, 5] * 0.01 - t0).min(), (tr[:, :, 5] * 0.01 - t0).max()))
-print("per workgroup: last wave out   mean %.2f max %.2f us" % ((t[:, :, 4].max(1) - t0).mean(), (t[:, :, 4].max() - t0)))
-print("level-2 list length per CU: mean %.1f max %d;  level-1: mean %.1f max %d;  chunks drawn per wave %d-%d" % (
-    tr[:, 0, 6].mean(), tr[:, 0, 6].max(), tr[:, 0, 7].mean(), tr[:, 0, 7].max(), tr[:, :, 8].min(), tr[:, :, 8].max()))
+print("per workgroup: last wave out   mean %.2f max %.2f us" % ((t[:, :, 3].max(1) - t0).mean(), (t[:, :, 3].max() - t0)))
+print("listed envs per CU: mean %.1f max %d;  chunks drawn per wave %d-%d" % (tr[:, 0, 6].mean(), tr[:, 0, 6].max(), tr[:, :, 8].min(), tr[:, :, 8].max()))
 print("main pass done, last wave of workgroups 0..31 (us):", np.round(t[:, :, 1].max(1) - t0, 1))
 b = 0
-print("workgroup 0, per wave (us since start): main done / decided / L2 done / L1 done")
+print("workgroup 0, per wave (us since start): main done / decided / list pass done")
 for w in range(nw):
-    print("  wave %2d  " % w, " ".join("%7.2f" % (t[b, w, k] - t0) for k in range(1, 5)))
+    print("  wave %2d  " % w, " ".join("%7.2f" % (t[b, w, k] - t0) for k in range(1, 4)))
 
 # per-chunk anatomy of the main pass (the first six chunks of every sampled wave; marks drain the memory counters)
 ck = tr[:, :, 16:64].reshape(32, nw, 6, 8).astype(np.float64) * 0.01
-ok = (ck[..., 6] > 0) & (ck[..., 0] > 0)
+ok = (ck[..., 6] > 0) & (ck[..., 0] >= t0)            # (marks older than this launch belong to earlier launches)
 names = ["loads arrive", "pump, meal, step-size rule, early stores", "integration", "x stores issued + sensor loads arrive", "epilogue compute", "stores drain"]
 for m in range(6):
     d = (ck[..., m + 1] - ck[..., m])[ok]
