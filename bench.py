@@ -33,7 +33,7 @@ METRIC = "env-steps/sec at batch=1M patients (1-min dt); fp64 glucose trace max-
 ALGO_BYTES = {"f64": 352, "f32": 184}       # algorithmic HBM bytes per env-step
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # vector (non-MFMA) peaks; the fp32 figure counts packed FMAs
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def shard_range(n_total, rank, world):
@@ -135,13 +135,34 @@ def cpu_baseline(n_envs, steps, n_sub, sensor, integ):
     return out
 
 
-def accuracy_block(env, pool, mt, ma, integ, n_sub, sensor, minutes, n_sample, seed=1):
+def _oracle_slice(args):
+    """one thread of the accuracy replay: the sampled envs [lo, hi) on the CPU oracle, step by step -> BG per step of the
+    SciPy-faithful DOPRI5 path, of a tight solve (classical RK4 at 48 sub-steps per minute) and of the kernel's own scheme"""
+    pid, sensor, z, pool_s, cho, K, st, integ, n_sub, with_tight = args
+    from oracle import t1d_oracle as O
+    envs = {"dopri": O.OracleEnv(pid, sensor=sensor, normals=z, integrator="dopri"),
+            "same": O.OracleEnv(pid, sensor=sensor, normals=z, integrator=integ, n_sub=n_sub)}
+    if with_tight:
+        envs["tight"] = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="rk4", n_sub=48)
+    out = {k: np.empty((K, len(pid))) for k in envs}
+    for e in envs.values():
+        e.reset()
+    for k in range(K):
+        c = cho[k * st:(k + 1) * st]
+        for name, e in envs.items():
+            out[name][k] = e.step(pool_s[k % len(pool_s)], None, c)["bg"]
+    return out
+
+
+def accuracy_block(env, pool, mt, ma, integ, n_sub, sensor, minutes, n_sample, seed=1, threads=8, rk4_too=True):
     """The accuracy half of the metric on the bench's own workload, outside the timed region: `n_sample` envs spread over
     the batch are replayed on the CPU oracle with the very normals, meals and actions the kernel used -- through the
-    SciPy-faithful DOPRI5 path (pinned to the reference's fixtures to ~1e-9) and through the oracle's restatement of the
-    kernel's own scheme."""
+    SciPy-faithful DOPRI5 path (pinned to the reference's fixtures to ~1e-9), through a tight solve of the same ODE (the
+    floor of the comparison: SciPy's own distance from the exact solution) and through the oracle's restatement of the
+    kernel's scheme.  The batch then runs the same minutes twice: with the integrator being benchmarked and, for the
+    record, with north_star's literal "fixed-step RK4" (classical RK4 on all 13 states, n_sub sub-steps per minute)."""
     import torch
-    from oracle import t1d_oracle as O
+    from concurrent.futures import ThreadPoolExecutor
     n = env.n
     rs = np.random.RandomState(seed)
     sample = np.unique(np.concatenate([np.arange(0, min(64, n)), np.arange(max(n - 64, 0), n), rs.randint(0, n, n_sample)]))[:n_sample]
@@ -157,23 +178,48 @@ def accuracy_block(env, pool, mt, ma, integ, n_sub, sensor, minutes, n_sample, s
                 cho[tt, j] = aa
     pool_s = [p[sidx].double().cpu().numpy() for p in pool]
     pid = env.patient_idx[sample]
-    ref = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="dopri")
-    same = O.OracleEnv(pid, sensor=sensor, normals=z, integrator=integ, n_sub=n_sub)
-    env.reset(); ref.reset(); same.reset()
-    worst_ref = np.zeros(len(sample)); worst_same = 0.0
-    for k in range(K):
-        env.step(pool[k % len(pool)])
-        r = ref.step(pool_s[k % len(pool)], None, cho[k * st:(k + 1) * st])
-        s = same.step(pool_s[k % len(pool)], None, cho[k * st:(k + 1) * st])
-        if k % 8 == 7 or k == K - 1:
-            bg = env.bg[sidx].double().cpu().numpy()
-            worst_ref = np.maximum(worst_ref, np.abs(bg - r["bg"]))
-            worst_same = max(worst_same, float(np.abs(bg - s["bg"]).max()))
-    return {"max_abs_err_mg_dl": float(worst_ref.max()), "p99_mg_dl": float(np.percentile(worst_ref, 99)),
-            "median_mg_dl": float(np.median(worst_ref)), "frac_envs_within_1e-3": float((worst_ref <= 1e-3).mean()),
-            "vs": "oracle DOPRI5 as SciPy drives it (rtol 1e-6; pinned to the reference's fixtures to ~1e-9)",
-            "hip_vs_oracle_same_scheme_max_mg_dl": worst_same,
-            "envs_sampled": int(len(sample)), "minutes": int(K * st), "quantity": "subcutaneous glucose (BG), per-env max over time"}
+    # the oracle replays on host threads (the C library releases the GIL; no fork once the GPU is initialised)
+    t0 = time.perf_counter()
+    nt = max(1, min(threads, len(sample) // 32))
+    cuts = np.linspace(0, len(sample), nt + 1).astype(int)
+    jobs = [(pid[lo:hi], sensor, np.ascontiguousarray(z[:, lo:hi]), [np.ascontiguousarray(p[lo:hi]) for p in pool_s],
+             np.ascontiguousarray(cho[:, lo:hi]), K, st, integ, n_sub, True) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    with ThreadPoolExecutor(nt) as ex:
+        parts = list(ex.map(_oracle_slice, jobs))
+    ref = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
+    cpu_s = time.perf_counter() - t0
+
+    def run(opts):
+        for name, value in opts:
+            env.set_option(name, value)
+        env.set_meals(mt, ma)
+        env.reset()
+        got = torch.empty(K, len(sample), dtype=torch.float64, device=env.device)
+        for k in range(K):
+            env.step(pool[k % len(pool)])
+            got[k] = env.bg[sidx].double()
+        return got.cpu().numpy()
+
+    def stats(got, against):
+        w = np.abs(got - against).max(axis=0)                  # per-env max over the run
+        return {"max_abs_err_mg_dl": float(w.max()), "p99_mg_dl": float(np.percentile(w, 99)), "median_mg_dl": float(np.median(w)),
+                "frac_envs_within_1e-3": float((w <= 1e-3).mean())}
+
+    got = run([])
+    out = stats(got, ref["dopri"])
+    out.update({"vs": "oracle DOPRI5 as SciPy drives it (rtol 1e-6; pinned to the reference's fixtures to ~1e-9)",
+                "hip_vs_oracle_same_scheme_max_mg_dl": float(np.abs(got - ref["same"]).max()),
+                "vs_tight_solve": stats(got, ref["tight"]),
+                "scipy_default_vs_tight_solve": dict(stats(ref["dopri"], ref["tight"]),
+                                                     note="the floor of the comparison: the reference's own integrator against classical RK4 at 48 sub-steps per minute, same envs"),
+                "envs_sampled": int(len(sample)), "minutes": int(K * st), "quantity": "subcutaneous glucose (BG), per-env max over time",
+                "oracle_cpu_seconds": cpu_s, "oracle_threads": nt})
+    rk4 = None
+    if rk4_too and integ != "rk4":
+        got4 = run([("integrator", 0)])
+        rk4 = dict(stats(got4, ref["dopri"]), vs_tight_solve=stats(got4, ref["tight"]), integrator="rk4", n_sub=n_sub,
+                   note="north_star's literal fixed-step RK4: classical RK4 on all 13 states, same envs, actions, meals and noise")
+    return out, rk4
 
 
 def main(argv=None):
@@ -203,8 +249,9 @@ def main(argv=None):
                     help="t1d_ctx_set_option switches applied after the ones above (tuning runs), e.g. --opt minute_launches=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
-    ap.add_argument("--accuracy-envs", type=int, default=256)
-    ap.add_argument("--accuracy-minutes", type=int, default=480)
+    ap.add_argument("--accuracy-envs", type=int, default=1024)
+    ap.add_argument("--accuracy-minutes", type=int, default=1440, help="north_star: a 24 h scenario")
+    ap.add_argument("--rk4-steps", type=int, default=200, help="timed launches of the north_star_rk4 leg (classical RK4, same workload)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
     ap.add_argument("--cpu-envs", type=int, default=32768)
@@ -228,8 +275,14 @@ def main(argv=None):
     # should not do
     integ_name = "rk4" if a.integrator == "rk4" or a.n_sub % 2 or a.n_sub > 8 else ("split" if a.fixed_step else "split_adaptive")
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_envs, a.cpu_steps, a.n_sub, a.sensor, integ_name)
+        # the reference's own Python path, timed in the build container by tools/time_reference_cpu.py (it cannot travel)
+        try:
+            with open(os.path.join(PROFILE_DIR, "reference_cpu.json")) as f:
+                cpu["reference_python"] = json.load(f)
+        except (OSError, ValueError):
+            pass
 
     import torch
     import torch.distributed as dist
@@ -279,10 +332,27 @@ def main(argv=None):
     g = torch.Generator(device="cpu"); g.manual_seed(7)
     pool = [(basal0 * 2.0 * torch.rand(n_global, generator=g, dtype=torch.float64)[env_offset:env_offset + n].to(dev, dt)).contiguous() for _ in range(8)]
 
-    accuracy = None
+    accuracy = rk4 = None
     if rank == 0 and not a.no_accuracy:
-        accuracy = accuracy_block(env, pool, mt, ma, integ, a.n_sub, a.sensor, a.accuracy_minutes, a.accuracy_envs)
+        accuracy, rk4 = accuracy_block(env, pool, mt, ma, integ, a.n_sub, a.sensor, a.accuracy_minutes, a.accuracy_envs)
+        if rk4 is not None:              # north_star's literal integrator on the same workload: time it too (integrator 0 is still set)
+            env.set_meals(mt, ma); env.reset()
+            for k in range(a.rk4_steps):
+                env.step(pool[k % 8])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(a.rk4_steps):
+                env.step(pool[k % 8])
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.rk4_steps
+            rk4.update({"kernel_ms": ms, "env_steps_per_s_this_gpu": n * st / (ms * 1e-3), "launches_timed": a.rk4_steps,
+                        "roofline_frac": ALGO_BYTES[a.dtype] * n * st / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
         env.set_meals(mt, ma)            # restart the meal cursors for the timed episode
+    if use_dist:
+        # rank 0 spent seconds in the accuracy replay: nobody starts warming up until it is back, so that every rank
+        # enters the timed region straight from its warm-up launches
+        dist.barrier()
     env.reset()
     for k in range(a.prewarm + a.warmup):
         env.step(pool[k % 8])
@@ -356,7 +426,7 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype], "valu": valu},
-            "accuracy": accuracy,
+            "accuracy": accuracy, "north_star_rk4": rk4,
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
         }

@@ -60,7 +60,9 @@ enum {
 /* bits of the device status word returned through t1d_sync */
 enum {
     T1D_ST_NORMALS_EXHAUSTED = 1,   /* host-normals mode ran past n_normals rows; zeros were used */
-    T1D_ST_NONFINITE = 2            /* some env's state became NaN/Inf */
+    T1D_ST_NONFINITE = 2,           /* some env's state became NaN/Inf */
+    T1D_ST_BAD_INDEX = 4,           /* t1d_model_rhs: a patient index outside the context's table (row 0 was used) */
+    T1D_ST_STALL = 8                /* a wave of a persistent kernel gave up waiting for its workgroup (never, by design): results invalid */
 };
 
 /* columns of one row of the patient table given to t1d_ctx_create (all double):
@@ -218,8 +220,8 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  *   insulin action makes the tissue compartment fast (:169-172) -- then level 2 (gut 2 n_sub, glucose n_sub): ~0.7 % of the
  *   env-minutes of RandomScenario days.  Max error against a tight solve 9e-4 mg/dL on random-meal days (level 1
  *   everywhere: 7e-3); a glucose state that reaches 0 is held there as the reference holds it.  In one-minute launches the
- *   lanes of level 2 are set aside and integrated together at the end of the launch; elsewhere a wave runs at the level
- *   of its most refined lane.
+ *   lanes of level 2 are set aside and integrated together at the end of the launch, in launches of several minutes they are
+ *   parked with their state and finished at the end; in the generic kernels a wave runs at the level of its most refined lane.
  *   0 = level 1 in every minute; 2 = as 1 but in place in every kernel; 3 = as 1, set aside at any batch size (tests).
  * "math": 1 (default) = exp-based gastric-emptying term and Newton-refined reciprocals in the ODE right-hand side;
  *   0 = ocml tanh and IEEE divisions written exactly as t1dpatient.py:138-140,171,178 writes them, classical RK4
@@ -230,10 +232,19 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  * "single_minute_kernel": 1 (default) = one-minute launches on the packed layout take the persistent kernels.
  * "s1_blocks": grid of those kernels (0 = one workgroup per compute unit).
  * "defer_min_chunks": threshold (64-env chunks per workgroup) from which the set-aside form is used.
- * "minute_launches": a step of several minutes (1 < minutes <= sample_time) on the packed layout as one such launch per
- *   minute, the outputs summed up in the output arrays: 1 (default) = for batches of "minute_launches_min_envs" (262 144)
- *   envs or more, where the set-aside form beats the in-place form of the generic kernel (1 Mi envs fp64, Dexcom:
- *   239 us per 3-minute step against 324); 0 = never; 2 = always. */
+ * "multi_minute_kernel": a step of several minutes (1 < minutes <= sample_time: the reference's Dexcom / GuardianRT
+ *   steps, env.py:75-81) on the packed layout in one launch of the persistent multi-minute kernel -- the state stays in
+ *   registers across the minutes; a lane that the step-size rule puts at level 2 leaves a record in LDS (its state at the
+ *   start of that minute) and the rest of its wave carries on at level 1; waves without a chunk to work on finish the
+ *   records, every lane at its own level, beside the last chunks.  1 (default) = fp64 batches of "multi_minute_min_envs"
+ *   (393 216) envs or more, where it beats the generic kernel (Dexcom steps, fp64: 147 against 184 us at 512 Ki envs, 257
+ *   against 339 at 1 Mi, 883 against 1254 at 4 Mi; level at 256 Ki; fp32 within 6 % of the generic kernel at every size);
+ *   0 = never (the generic kernel: a wave runs at the level of its most refined lane); 2 = always.
+ *   "park_cap": records per workgroup (0 = what fits in LDS beside the tables; a flagged lane that finds none free is
+ *   taken again from its loads at the end of the launch, in place).
+ * "rollout_launches": t1d_rollout_pid / t1d_rollout_bb as one launch of that kernel per step, the controller fused into
+ *   it: 1 (default) = fp64 batches of "rollout_launches_min_envs" (393 216) envs or more; 0 = never (all steps inside one
+ *   launch of the generic roll-out kernel); 2 = always. */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Host-only helper (no device needed): the tables of the split integrator for one patient row

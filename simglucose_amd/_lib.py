@@ -12,7 +12,7 @@ SOURCES = [os.path.join(_PKG, "csrc", "t1d_abi.hip"), os.path.join(_PKG, "csrc",
            os.path.join(_ROOT, "include", "t1d.h")]
 
 T1D_F64, T1D_F32 = 0, 1
-T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE = 1, 2
+T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE, T1D_ST_BAD_INDEX, T1D_ST_STALL = 1, 2, 4, 8
 ABI_VERSION = 3
 T1D_BATCH_NO_PUMP = 2
 T1D_BATCH_NO_REFILL_DUE = 4

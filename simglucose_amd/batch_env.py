@@ -128,6 +128,7 @@ class BatchedT1DSimEnv:
             self.set_normals(normals)
         self._closed = False
         self._clock = None         # minutes since the last FULL reset while every env shares one clock, else None
+        self._iver = None          # version counter of the integer state tensors when the shadow clock was last valid
         self._flags0 = b.flags
         self.window = int(60 / self.sample_time)            # samples a custom reward function sees (env.py:100)
         self._hist = self._hist_pos = self._hist_cnt = None
@@ -234,6 +235,7 @@ class BatchedT1DSimEnv:
         self._clock = 0 if mask is None else None
         with torch.cuda.device(self.device):
             _lib.check(self._L.t1d_reset(self._ctx, C.byref(b), mptr, int(self.random_init_bg), self._stream()))
+        self._iver = self.istate._version
         b.x0_override = None
         self._keep = (keep, mask)
         self._hist_reset(mask)
@@ -260,6 +262,10 @@ class BatchedT1DSimEnv:
         else:
             b.cho = None
         b.flags = self._flags0
+        if self._clock is not None and self.istate._version != self._iver:
+            # somebody wrote env.t / env.meta / env.next_meal through torch since the shadow clock was taken (kernel
+            # launches do not move the version counter): the envs' own clocks decide again
+            self._clock = None
         if self._clock is not None:
             # every env shares the clock: the host knows whether a sample in (t, t + minutes] opens a noise block
             st, S = self.minutes_per_step, int(150 // self.sample_time)
@@ -281,11 +287,18 @@ class BatchedT1DSimEnv:
 
     def info(self):
         """live views of the device outputs and state: read-only for the caller (the reference's info['patient_state']
-        is the solver's own array too, env.py:112); writing env.t / env.x directly desynchronises the host's shadow
-        clock -- go through load_state_dict, which drops it."""
+        is the solver's own array too, env.py:112).  The clock comes as a COPY: the wrapper shadows it on the host to
+        skip the noise-block refill pre-kernel, so the device array is not the caller's to edit -- a caller who does
+        edit env.t / env.x says so with invalidate_clock() (or goes through load_state_dict)."""
         return {"sample_time": self.sample_time, "bg": self.bg, "lbgi": self.lbgi, "hbgi": self.hbgi,
                 "risk": self.risk, "meal": self.meal, "insulin": self.insulin, "patient_state": self.x,
-                "t": self.t}
+                "t": self.t.clone()}
+
+    def invalidate_clock(self):
+        """forget the host's shadow clock: the next steps check every env's own clock for due noise-block refills again.
+        (In-place torch edits of env.t / env.meta / env.next_meal are noticed through the tensors' version counter; this
+        is for writes the counter cannot see, e.g. through a raw pointer.)"""
+        self._clock = None
 
     @staticmethod
     def _set_trace(p, trace, n_steps):
@@ -395,6 +408,8 @@ class BatchedT1DSimEnv:
         pid = t(patient_idx, torch.int32); args = [t(v) for v in (cho, insulin, last_qsto, last_food)]
         if pid.shape != (m,) or any(v.shape != (m,) for v in args):
             raise ValueError("patient_idx, cho, insulin, last_qsto, last_food must have m entries")
+        if m and (int(pid.min()) < 0 or int(pid.max()) >= len(self.names)):
+            raise ValueError("patient_idx out of range for the context's table of %d patients" % len(self.names))
         out = torch.empty(13, m, dtype=self.dtype, device=self.device)
         p = lambda v: C.c_void_p(v.data_ptr())
         with torch.cuda.device(self.device):
@@ -420,18 +435,29 @@ class BatchedT1DSimEnv:
         return st.value
 
     # ------------------------------------------------------------------ checkpoint
+    STATE_FORMAT = 3           # = the ABI version whose state words the checkpoint holds (prev_risk, cgm0: since 3)
+
     def state_dict(self):
         sd = {k: getattr(self, k).clone() for k in _STATE_KEYS + ("cgm", "cgm0")}
+        sd["format"] = self.STATE_FORMAT
         if self._hist is not None:
             sd.update({k: getattr(self, k).clone() for k in ("_hist", "_hist_pos", "_hist_cnt")})
         return sd
 
     def load_state_dict(self, sd):
+        fmt = sd.get("format")
+        if fmt != self.STATE_FORMAT or any(k not in sd for k in _STATE_KEYS + ("cgm", "cgm0")):
+            raise _lib.T1DError("checkpoint format %r is not %d (checkpoints written before ABI 3 carry prev_cgm instead of "
+                                "prev_risk and no cgm0): re-create it with this version" % (fmt, self.STATE_FORMAT))
         for k in _STATE_KEYS + ("cgm", "cgm0"):
             getattr(self, k).copy_(sd[k])
-        for k in ("_hist", "_hist_pos", "_hist_cnt"):
-            if getattr(self, k) is not None and k in sd:
-                getattr(self, k).copy_(sd[k])
+        if self._hist is not None:
+            if all(k in sd for k in ("_hist", "_hist_pos", "_hist_cnt")):
+                for k in ("_hist", "_hist_pos", "_hist_cnt"):
+                    getattr(self, k).copy_(sd[k])
+            else:
+                # the checkpoint was taken without a CGM history: what the ring can honestly hold is the last observation
+                self._hist_after_rollout()
         self._clock = None
 
     def close(self):

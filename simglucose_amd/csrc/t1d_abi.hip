@@ -29,7 +29,7 @@ struct t1d_ctx {
     int math = 1;            // RHS arithmetic variant (t1d_ctx_set_option "math")
     int n_cu = 256;
     int lds_per_block = 65536;   // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
-    std::vector<const void*> lds_allowed;   // kernels whose dynamic-LDS ceiling has been raised above 64 KiB
+    std::vector<std::pair<const void*, size_t>> lds_allowed;   // kernels whose dynamic-LDS ceiling has been raised above 64 KiB, and to what
     int s1_blocks = 0;       // > 0: grid of the single-minute kernels (tests exercise many chunks per block)
     int split_refill = 1;    // 1 = noise-block refills run in their own kernel ahead of a refill-free step kernel
     int adaptive_gut = 1;    // 1 (default) = the split integrator picks its step sizes per minute and env; 0 = level 1 everywhere
@@ -40,8 +40,11 @@ struct t1d_ctx {
     double* d_prop64 = nullptr; float* d_prop32 = nullptr;   // [kPropRows(split_nsub)][np_pad]
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
     int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of level 2 aside from this many chunks per CU up
-    int minute_launches = 1;         // steps of several minutes as one single-minute launch per minute: 0 never, 1 from minute_launches_min_envs envs up, 2 always
-    int minute_launches_min_envs = 262144;
+    int multi_minute_kernel = 1;     // steps of several minutes (minutes <= sample_time) on the packed layout through the persistent kernel with the state in registers across the minutes: 0 never (generic kernel), 1 = fp64 batches of multi_minute_min_envs envs or more, 2 always
+    int multi_minute_min_envs = 393216;
+    int park_cap = 0;                // records for set-aside lanes per workgroup of that kernel (0 = what fits in LDS; tests force the overflow path with a small one)
+    int rollout_launches = 1;        // closed-loop roll-outs as one launch of that kernel per step: 0 never (all steps inside one launch of the generic kernel), 1 from rollout_launches_min_envs envs up, 2 always
+    int rollout_launches_min_envs = 393216;
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
 };
@@ -337,8 +340,11 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         {"math", &t1d_ctx::math, 0, 1},
         {"split_refill", &t1d_ctx::split_refill, 0, 1},
         {"defer_min_chunks", &t1d_ctx::defer_min_chunks, 0, 65535},
-        {"minute_launches", &t1d_ctx::minute_launches, 0, 2},
-        {"minute_launches_min_envs", &t1d_ctx::minute_launches_min_envs, 0, 1 << 28},
+        {"multi_minute_kernel", &t1d_ctx::multi_minute_kernel, 0, 2},
+        {"multi_minute_min_envs", &t1d_ctx::multi_minute_min_envs, 0, 1 << 28},
+        {"park_cap", &t1d_ctx::park_cap, 0, 65535},
+        {"rollout_launches", &t1d_ctx::rollout_launches, 0, 2},
+        {"rollout_launches_min_envs", &t1d_ctx::rollout_launches_min_envs, 0, 1 << 28},
         {"s1_blocks", &t1d_ctx::s1_blocks, 0, 65535},
         {"adaptive_gut", &t1d_ctx::adaptive_gut, 0, 3},
         {"single_minute_kernel", &t1d_ctx::single_minute_kernel, 0, 1},
@@ -414,19 +420,9 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.pump.min_bolus = (T)c->pump[0]; a.pump.max_bolus = (T)c->pump[1]; a.pump.inc_bolus = (T)c->pump[2];
     a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
     a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
-    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags; a.sub = 0;
+    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags;
     a.prop = sizeof(T) == 8 ? (const T*)c->d_prop64 : (const T*)c->d_prop32;
     a.prop_rows = c->split_nsub ? kPropRows(c->split_nsub) : 0; a.np_pad = c->np_pad;
-    return a;
-}
-
-// minute `sub` of a `minutes`-minute step taken as one single-minute launch per minute
-template <typename T>
-static KArgs<T> make_args_sub(const t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, int sub)
-{
-    KArgs<T> a = make_args<T>(c, b, minutes, n_sub);
-    a.sub = sub;
-    if (a.cho) a.cho += (size_t)sub * (size_t)b->n;
     return a;
 }
 
@@ -445,13 +441,19 @@ extern "C" int t1d_reset(t1d_ctx* c, const t1d_batch* b, const uint8_t* mask, in
     return T1D_OK;
 }
 
-// more than 64 KiB of dynamic LDS has to be allowed per kernel (once; a context belongs to one device)
+// more than 64 KiB of dynamic LDS has to be allowed per kernel (a context belongs to one device)
 static hipError_t allow_lds(t1d_ctx* c, const void* fn, size_t bytes)
 {
     if (bytes <= 65536) return hipSuccess;
-    for (const void* f : c->lds_allowed) if (f == fn) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_block - 512);
-    if (e == hipSuccess) c->lds_allowed.push_back(fn);
+    for (auto& f : c->lds_allowed)
+        if (f.first == fn) {
+            if (f.second >= bytes) return hipSuccess;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) f.second = bytes;
+            return e;
+        }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) c->lds_allowed.push_back({fn, bytes});
     return e;
 }
 
@@ -465,6 +467,92 @@ static int pick_variant(const t1d_ctx* c, bool split, int dtype)
     return dtype == T1D_F32 ? 6 : 7;           // with per-lane step sizes the parameters fit in VGPRs in fp32 only
 }
 
+// What the persistent kernels of a call need: the split integrator on the packed layout, the noise refill kept out of
+// the step kernel, tables that fit in LDS.
+struct PersistPlan {
+    bool ok = false;
+    int stride = 32, nchunks = 0, blocks = 0, per_block = 0;
+    size_t dyn_tables = 0;
+};
+
+static bool is_packed(const t1d_batch* b, size_t esz)
+{
+    const char* xb = (const char*)b->x;
+    const size_t rowb = (size_t)b->n * esz;
+    return (const char*)b->planned == xb + 13 * rowb && (const char*)b->last_qsto == xb + 14 * rowb &&
+           (const char*)b->last_food == xb + 15 * rowb && (const char*)b->last_cgm == xb + 16 * rowb &&
+           (const char*)b->prev_risk == xb + 17 * rowb && (const char*)b->pts == xb + 18 * rowb &&
+           b->next_meal && (const char*)b->meta == (const char*)b->t + (size_t)b->n * 4 &&
+           (const char*)b->next_meal == (const char*)b->t + (size_t)b->n * 8 &&
+           (size_t)kPackedRows * rowb < ((size_t)1 << 32);
+}
+
+static PersistPlan plan_persistent(const t1d_ctx* c, const t1d_batch* b, int n_sub, bool split, bool split_refill)
+{
+    PersistPlan p;
+    const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
+    if (!(split_refill && split && c->single_minute_kernel && is_packed(b, esz)) || (T1D_AB_FLAGS && (b->flags & 0x600))) return p;
+    p.stride = c->np <= 32 ? 32 : 64;
+    p.dyn_tables = (size_t)(DP_COUNT + kPropRows(n_sub)) * p.stride * esz;
+    if (p.dyn_tables + 512 > (size_t)c->lds_per_block) return p;
+    p.nchunks = (int)((b->n + 63) / 64);
+    p.blocks = c->s1_blocks > 0 ? c->s1_blocks : c->n_cu;           // one workgroup of 4 x T1D_S1_WAVES waves per CU
+    if (p.blocks > p.nchunks) p.blocks = p.nchunks;
+    p.per_block = (p.nchunks + p.blocks - 1) / p.blocks;
+    p.ok = true;
+    return p;
+}
+
+// LDS of stepn_kernel beside the tables: the redo map (one bit per env of a workgroup's share) and the records -- as many as
+// fit, never more than the workgroup's env-minutes.  -> records (a multiple of 64), or -1 where the tables leave no room.
+static int stepn_park_cap(const t1d_ctx* c, const PersistPlan& p, size_t esz, int minutes, size_t* dyn)
+{
+    const size_t rec = (size_t)kSnParkT * esz + (size_t)kSnParkI * sizeof(int);
+    const size_t fixed = p.dyn_tables;
+    if (p.stride != 32 || fixed + 1024 > (size_t)c->lds_per_block) return -1;
+    const size_t map = (size_t)p.per_block * 8 + 8;         // the redo map: one bit per env of the workgroup's share
+    if (fixed + map + 1024 > (size_t)c->lds_per_block) return -1;
+    long long cap = (long long)(((size_t)c->lds_per_block - 1024 - fixed - map) / rec) / 64 * 64;
+    const long long share = ((long long)p.per_block * 64 * minutes + 63) / 64 * 64;
+    if (cap > share) cap = share;
+    if (c->park_cap > 0 && cap > (c->park_cap + 63) / 64 * 64) cap = (c->park_cap + 63) / 64 * 64;
+    *dyn = fixed + (size_t)cap * rec + map;
+    return (int)cap;
+}
+
+template <typename T>
+static PidArgs<T> no_ctrl()
+{
+    PidArgs<T> c;
+    std::memset(&c, 0, sizeof(c));
+    return c;
+}
+
+// one launch of stepn_kernel: a step of `minutes` minutes, or (CTRL) one closed-loop step
+template <typename T, bool EXTRA, bool CTRL>
+static int launch_stepn(t1d_ctx* c, const t1d_batch* b, const PersistPlan& p, int cap, size_t dyn, int minutes, int n_sub, const PidArgs<T>& pa, hipStream_t s)
+{
+    T1D_HIP(allow_lds(c, (const void*)stepn_kernel<T, EXTRA, CTRL>, dyn));
+    const int mode = (c->adaptive_gut != 0 ? 1 : 0) | (c->adaptive_gut == 2 ? 2 : 0);
+    hipLaunchKernelGGL((stepn_kernel<T, EXTRA, CTRL>), dim3(p.blocks), dim3(sn_threads<T>()), dyn, s, make_args<T>(c, b, minutes, n_sub), pa,
+                       p.nchunks, cap, mode);
+    return T1D_OK;
+}
+
+template <typename T>
+static void launch_refill(const t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, hipStream_t s)
+{
+    hipLaunchKernelGGL(refill_kernel<T>, grid_for(b->n), dim3(kBlock), 0, s, make_args<T>(c, b, minutes, n_sub));
+}
+
+// the generic kernels keep the propagator table [rows][np_pad] in dynamic LDS (next to a static parameter table in the
+// LDS-parameter variants): does it fit?
+static bool generic_split_fits(const t1d_ctx* c, int n_sub, size_t esz, size_t* dyn)
+{
+    *dyn = (size_t)kPropRows(n_sub) * c->np_pad * esz;
+    return *dyn + (size_t)DP_COUNT * kMaxPatients * esz + 1024 <= (size_t)c->lds_per_block;
+}
+
 extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, void* stream)
 {
     int rc = check_batch("t1d_step", c, b, true);
@@ -474,81 +562,79 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     hipStream_t s = (hipStream_t)stream;
     if (c->integrator == 1 && !use_split(c, n_sub))
         return fail(T1D_E_INVALID, "t1d_step: the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
-    const bool split = use_split(c, n_sub);
+    bool split = use_split(c, n_sub);
     const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
-    size_t dyn = 0;
     if (split) {
         rc = ensure_split(c, n_sub);
         if (rc) return rc;
-        dyn = (size_t)kPropRows(n_sub) * c->np_pad * esz;
-        if (dyn > 65536) return fail(T1D_E_INVALID, "t1d_step: split tables exceed 64 KiB of LDS (n_patients x n_sub too large); use integrator 0");
     }
-    const int variant = pick_variant(c, split, b->dtype);
-    const char* xb = (const char*)b->x;
-    const size_t rowb = (size_t)b->n * esz;
-    const bool packed = (const char*)b->planned == xb + 13 * rowb && (const char*)b->last_qsto == xb + 14 * rowb &&
-                        (const char*)b->last_food == xb + 15 * rowb && (const char*)b->last_cgm == xb + 16 * rowb &&
-                        (const char*)b->prev_risk == xb + 17 * rowb && (const char*)b->pts == xb + 18 * rowb &&
-                        b->next_meal && (const char*)b->meta == (const char*)b->t + (size_t)b->n * 4 &&
-                        (const char*)b->next_meal == (const char*)b->t + (size_t)b->n * 8 &&
-                        (size_t)kPackedRows * rowb < ((size_t)1 << 32);
+    int variant = pick_variant(c, split, b->dtype);
     // At most one CGM sample per launch (minutes <= sample_time): the noise-block refill runs as its own
     // kernel ahead of a step kernel compiled without it, unless the caller vouches that none is due.
     const bool split_refill = variant != 0 && c->split_refill && minutes <= (int)c->sensor[5];
-    if (split_refill && !(b->flags & T1D_BATCH_NO_REFILL_DUE)) {
-        if (b->dtype == T1D_F64) hipLaunchKernelGGL(refill_kernel<double>, grid_for(b->n), dim3(kBlock), 0, s, make_args<double>(c, b, minutes, n_sub));
-        else hipLaunchKernelGGL(refill_kernel<float>, grid_for(b->n), dim3(kBlock), 0, s, make_args<float>(c, b, minutes, n_sub));
+    const PersistPlan p = plan_persistent(c, b, n_sub, split, split_refill);
+    size_t dyn_n = 0;
+    // (measured, Dexcom steps: fp64 147 against 184 us at 512 Ki envs, 257 against 339 at 1 Mi, 883 against 1254 at 4 Mi, level
+    // at 256 Ki, the generic kernel ahead below; fp32 within 6 % of the generic kernel at every size)
+    const bool want_n = c->multi_minute_kernel == 2 || (c->multi_minute_kernel == 1 && b->dtype == T1D_F64 && b->n >= c->multi_minute_min_envs);
+    const int cap = p.ok && minutes > 1 && want_n ? stepn_park_cap(c, p, esz, minutes, &dyn_n) : -1;
+    const bool persistent = p.ok && (minutes == 1 || cap >= 0);
+    size_t dyn = 0;
+    if (!persistent && split && !generic_split_fits(c, n_sub, esz, &dyn)) {
+        // the generic kernel cannot hold this table (many patients x many sub-steps): classical RK4 when the caller left
+        // the choice of integrator to the library
+        if (c->integrator == 1) return fail(T1D_E_INVALID, "t1d_step: split tables exceed the LDS of a workgroup (n_patients x n_sub too large); use integrator 0 or -1");
+        split = false; dyn = 0;
+        variant = pick_variant(c, split, b->dtype);
     }
-    // one simulated minute per launch with the split integrator: the persistent early-store kernels
-    // (a step of several minutes of a large batch too: there the set-aside form of the step-size rule, one launch per
-    // minute, beats the in-place form of step_kernel, whose waves run at the level of their most refined lane)
-    const bool by_minute = minutes == 1 || c->minute_launches == 2 || (c->minute_launches == 1 && b->n >= c->minute_launches_min_envs);
-    if (split_refill && split && by_minute && c->single_minute_kernel && packed && !(T1D_AB_FLAGS && (b->flags & 0x600))) {
-        const int stride = c->np <= 32 ? 32 : 64;
-        const size_t dyn1 = (size_t)(DP_COUNT + kPropRows(n_sub)) * stride * esz;
-        if (dyn1 + 512 <= (size_t)c->lds_per_block) {
-            const int nchunks = (int)((b->n + 63) / 64);
-            int blocks = c->s1_blocks > 0 ? c->s1_blocks : c->n_cu;           // one workgroup of 4 x T1D_S1_WAVES waves per CU
-            if (blocks > nchunks) blocks = nchunks;
-            const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
-            const bool tiered = c->adaptive_gut != 0;
-            // per-minute step sizes: lanes of level 2 set aside and integrated together at the end of the launch
-            // (step1d_kernel) where the list of the CU's envs fits next to the tables; adaptive_gut = 2 asks for the
-            // in-place form, 3 for the set-aside form at any batch size
-            const int per_block = (nchunks + blocks - 1) / blocks;
-            const size_t dyn1d = dyn1 + (size_t)kS1DPark * (18 * esz + 3 * sizeof(int)) + (size_t)per_block * 64 * sizeof(uint16_t);
-            const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
-                               stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
+    if (split_refill && !(b->flags & T1D_BATCH_NO_REFILL_DUE)) {
+        if (b->dtype == T1D_F64) launch_refill<double>(c, b, minutes, n_sub, s); else launch_refill<float>(c, b, minutes, n_sub, s);
+    }
+    const bool extra = b->lbgi || b->hbgi || b->risk || b->meal || b->insulin;
+    if (persistent && minutes > 1) {
+        // a step of several minutes: state in registers across the minutes, lanes of level 2 parked and finished at the end
+        if (b->dtype == T1D_F64) rc = extra ? launch_stepn<double, true, false>(c, b, p, cap, dyn_n, minutes, n_sub, no_ctrl<double>(), s)
+                                            : launch_stepn<double, false, false>(c, b, p, cap, dyn_n, minutes, n_sub, no_ctrl<double>(), s);
+        else rc = extra ? launch_stepn<float, true, false>(c, b, p, cap, dyn_n, minutes, n_sub, no_ctrl<float>(), s)
+                        : launch_stepn<float, false, false>(c, b, p, cap, dyn_n, minutes, n_sub, no_ctrl<float>(), s);
+        if (rc) return rc;
+        T1D_HIP(hipGetLastError());
+        return T1D_OK;
+    }
+    if (persistent) {
+        // one simulated minute per launch with the split integrator: the persistent early-store kernels
+        const int stride = p.stride, nchunks = p.nchunks, blocks = p.blocks, per_block = p.per_block;
+        const size_t dyn1 = p.dyn_tables;
+        const bool tiered = c->adaptive_gut != 0;
+        // per-minute step sizes: lanes of level 2 set aside and integrated together at the end of the launch
+        // (step1d_kernel) where the list of the CU's envs fits next to the tables; adaptive_gut = 2 asks for the
+        // in-place form, 3 for the set-aside form at any batch size
+        const size_t dyn1d = dyn1 + (size_t)kS1DPark * (18 * esz + 3 * sizeof(int)) + (size_t)per_block * 64 * sizeof(uint16_t);
+        const bool defer = tiered && (c->adaptive_gut == 3 || (c->adaptive_gut == 1 && per_block >= c->defer_min_chunks)) &&
+                           stride == 32 && per_block * 64 <= 65536 && dyn1d + 512 <= (size_t)c->lds_per_block;
 #define T1D_LAUNCH_S1(TT, ST, EX, TI) do { T1D_HIP(allow_lds(c, (const void*)step1_kernel<TT, ST, EX, TI>, dyn1)); \
-        hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(s1_threads<TT>()), dyn1, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
-#define T1D_LAUNCH_S1D_M(TT, EX, MU) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX, MU>, dyn1d)); \
-        hipLaunchKernelGGL((step1d_kernel<TT, EX, MU>), dim3(blocks), dim3(s1d_threads<TT>()), dyn1d, s, make_args_sub<TT>(c, b, minutes, n_sub, sub), nchunks); } while (0)
-#define T1D_LAUNCH_S1D(TT, EX) do { if (minutes == 1) T1D_LAUNCH_S1D_M(TT, EX, false); else T1D_LAUNCH_S1D_M(TT, EX, true); } while (0)
+        hipLaunchKernelGGL((step1_kernel<TT, ST, EX, TI>), dim3(blocks), dim3(s1_threads<TT>()), dyn1, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
+#define T1D_LAUNCH_S1D(TT, EX) do { T1D_HIP(allow_lds(c, (const void*)step1d_kernel<TT, EX>, dyn1d)); \
+        hipLaunchKernelGGL((step1d_kernel<TT, EX>), dim3(blocks), dim3(s1d_threads<TT>()), dyn1d, s, make_args<TT>(c, b, minutes, n_sub), nchunks); } while (0)
 #define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \
                                else { if (extra) T1D_LAUNCH_S1(TT, ST, true, false); else T1D_LAUNCH_S1(TT, ST, false, false); } } while (0)
 #define T1D_S1D_BY(TT) do { if (extra) T1D_LAUNCH_S1D(TT, true); else T1D_LAUNCH_S1D(TT, false); } while (0)
-            // (steps of several minutes: only in the set-aside form -- otherwise the generic kernel below takes them)
-            for (int sub = 0; sub < (minutes == 1 || defer ? minutes : 0); ++sub) {
-                if (defer) {
-                    if (b->dtype == T1D_F64) T1D_S1D_BY(double); else T1D_S1D_BY(float);
-                } else if (b->dtype == T1D_F64) {
-                    if (stride == 32) T1D_S1_BY(double, 32); else T1D_S1_BY(double, 64);
-                } else {
-                    if (stride == 32) T1D_S1_BY(float, 32); else T1D_S1_BY(float, 64);
-                }
-            }
+        if (defer) {
+            if (b->dtype == T1D_F64) T1D_S1D_BY(double); else T1D_S1D_BY(float);
+        } else if (b->dtype == T1D_F64) {
+            if (stride == 32) T1D_S1_BY(double, 32); else T1D_S1_BY(double, 64);
+        } else {
+            if (stride == 32) T1D_S1_BY(float, 32); else T1D_S1_BY(float, 64);
+        }
 #undef T1D_S1D_BY
 #undef T1D_S1_BY
 #undef T1D_LAUNCH_S1D
-#undef T1D_LAUNCH_S1D_M
 #undef T1D_LAUNCH_S1
-            if (minutes == 1 || defer) {
-                T1D_HIP(hipGetLastError());
-                return T1D_OK;
-            }
-        }
+        T1D_HIP(hipGetLastError());
+        return T1D_OK;
     }
-#define T1D_LAUNCH_STEP(V, TT, RF) hipLaunchKernelGGL((step_kernel<V, TT, RF>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub))
+#define T1D_LAUNCH_STEP(V, TT, RF) do { T1D_HIP(allow_lds(c, (const void*)step_kernel<V, TT, RF>, dyn)); \
+        hipLaunchKernelGGL((step_kernel<V, TT, RF>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub)); } while (0)
 #define T1D_BY_VARIANT(TT, RF, V67) do { switch (variant) { case 0: T1D_LAUNCH_STEP(0, TT, RF); break; case 3: T1D_LAUNCH_STEP(3, TT, RF); break; \
                                                             case 4: T1D_LAUNCH_STEP(4, TT, RF); break; default: T1D_LAUNCH_STEP(V67, TT, RF); break; } } while (0)
     if (split_refill) {          // the refill ran ahead (or none is due): the kernel compiled without it
@@ -603,17 +689,49 @@ static int launch_rollout(const char* who, t1d_ctx* c, const t1d_batch* b, int n
     hipStream_t s = (hipStream_t)stream;
     if (c->integrator == 1 && !use_split(c, n_sub))
         return fail(T1D_E_INVALID, std::string(who) + ": the split integrator needs math = 1 and n_sub in {2, 4, 6, 8}");
-    const bool split = use_split(c, n_sub);
-    size_t dyn = 0;
+    bool split = use_split(c, n_sub);
+    const size_t esz = b->dtype == T1D_F64 ? 8 : 4;
     if (split) {
         rc = ensure_split(c, n_sub);
         if (rc) return rc;
-        dyn = (size_t)kPropRows(n_sub) * c->np_pad * (b->dtype == T1D_F64 ? 8 : 4);
-        if (dyn > 65536) return fail(T1D_E_INVALID, std::string(who) + ": split tables exceed 64 KiB of LDS; use integrator 0");
     }
-    const int variant = pick_variant(c, split, b->dtype);
-#define T1D_LAUNCH_ROLL(V, TT, MK) hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, \
-                                                      make_args<TT>(c, b, minutes, n_sub), MK())
+    int variant = pick_variant(c, split, b->dtype);
+    // Large batches: one launch of the persistent multi-minute kernel per step, the controller in its prologue -- the
+    // step-size rule's lanes of level 2 are set aside, where the all-steps-in-one-launch kernel runs each wave at the level
+    // of its most refined lane.  The noise-block refill goes ahead of every step as in t1d_step (the clocks are the envs').
+    const bool per_step = c->rollout_launches == 2 || (c->rollout_launches == 1 && b->dtype == T1D_F64 && b->n >= c->rollout_launches_min_envs);
+    const bool split_refill = variant != 0 && c->split_refill && minutes <= (int)c->sensor[5];
+    if (per_step && c->multi_minute_kernel) {       // (a step of one minute too: the kernel takes any minutes >= 1)
+        const PersistPlan p = plan_persistent(c, b, n_sub, split, split_refill);
+        size_t dyn_n = 0;
+        const int cap = p.ok ? stepn_park_cap(c, p, esz, minutes, &dyn_n) : -1;
+        if (cap >= 0) {
+            for (int k = 0; k < n_steps; ++k) {
+                if (b->dtype == T1D_F64) {
+                    launch_refill<double>(c, b, minutes, n_sub, s);
+                    PidArgs<double> pa = mk64();
+                    pa.n_steps = 1; pa.trace_row += k;
+                    rc = launch_stepn<double, true, true>(c, b, p, cap, dyn_n, minutes, n_sub, pa, s);
+                } else {
+                    launch_refill<float>(c, b, minutes, n_sub, s);
+                    PidArgs<float> pa = mk32();
+                    pa.n_steps = 1; pa.trace_row += k;
+                    rc = launch_stepn<float, true, true>(c, b, p, cap, dyn_n, minutes, n_sub, pa, s);
+                }
+                if (rc) return rc;
+            }
+            T1D_HIP(hipGetLastError());
+            return T1D_OK;
+        }
+    }
+    size_t dyn = 0;
+    if (split && !generic_split_fits(c, n_sub, esz, &dyn)) {
+        if (c->integrator == 1) return fail(T1D_E_INVALID, std::string(who) + ": split tables exceed the LDS of a workgroup; use integrator 0 or -1");
+        split = false; dyn = 0;
+        variant = pick_variant(c, split, b->dtype);
+    }
+#define T1D_LAUNCH_ROLL(V, TT, MK) do { T1D_HIP(allow_lds(c, (const void*)rollout_pid_kernel<V, TT>, dyn)); \
+        hipLaunchKernelGGL((rollout_pid_kernel<V, TT>), grid_for(b->n), dim3(kBlock), dyn, s, make_args<TT>(c, b, minutes, n_sub), MK()); } while (0)
 #define T1D_BY_VARIANT(TT, MK, V67) do { switch (variant) { case 0: T1D_LAUNCH_ROLL(0, TT, MK); break; case 3: T1D_LAUNCH_ROLL(3, TT, MK); break; \
                                                             case 4: T1D_LAUNCH_ROLL(4, TT, MK); break; default: T1D_LAUNCH_ROLL(V67, TT, MK); break; } } while (0)
     if (b->dtype == T1D_F64) T1D_BY_VARIANT(double, mk64, 7);
@@ -717,7 +835,7 @@ extern "C" int t1d_model_rhs(t1d_ctx* c, int dtype, int64_t n, int math, const v
     T1D_HIP(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
 #define T1D_RHS(M, TT, PAR) hipLaunchKernelGGL((rhs_kernel<M, TT>), grid_for(n), dim3(kBlock), 0, s, n, (const TT*)x, pid, (const TT*)cho, \
-                                               (const TT*)insulin, (const TT*)last_qsto, (const TT*)last_food, (TT*)dxdt, (const TT*)PAR)
+                                               (const TT*)insulin, (const TT*)last_qsto, (const TT*)last_food, (TT*)dxdt, (const TT*)PAR, c->np, c->d_status)
     if (dtype == T1D_F64) { if (math) T1D_RHS(1, double, c->d_par64); else T1D_RHS(0, double, c->d_par64); }
     else { if (math) T1D_RHS(1, float, c->d_par32); else T1D_RHS(0, float, c->d_par32); }
 #undef T1D_RHS

@@ -496,16 +496,32 @@ __device__ __forceinline__ bool tier_level2(P& p, const MinuteIn<T>& u, const T 
 // registers across minutes; the single-minute kernel sets level-2 lanes aside instead).
 // HAVE_F1: the caller has evaluated kgut_flux at the start of the minute already (for the step-size rule) and hands it
 // in.  (Keeping the rule's first glucose stage as well costs three register pairs across the gut steps: spills.)
-template <int LEVEL, typename T, typename P, typename PR, bool HAVE_F1 = false>
-__device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0),
-                                            bool refine = false)
+// HC (levels 1 and 2): the step sizes come from five words the host has formed with the very expressions below (split_step_sizes)
+// and the kernel keeps in LDS -- a minute loop otherwise either repeats three IEEE divisions per minute or carries ten
+// more registers across everything.
+template <typename T> __host__ __device__ inline void split_step_sizes(int nh, T (&c)[5])
 {
+    const T h = T(1) / T(nh);
+    c[0] = h; c[1] = T(0.5) * h; c[2] = h / T(6); c[3] = h + h; c[4] = (h + h) / T(6);
+}
+template <int LEVEL, typename T, typename P, typename PR, bool HAVE_F1 = false, bool HC = false>
+__device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0),
+                                            bool refine = false, const T* hc = nullptr)
+{
+    static_assert(!HC || LEVEL != 0, "step sizes from memory: compile-time levels only");
     const bool r2 = LEVEL == 2 || (LEVEL == 0 && refine);        // this lane at level 2
     const int sb = r2 ? 1 : 2;                                    // propagator blocks per glucose half step
     const int nh = r2 ? 2 * n_sub : n_sub;                        // glucose half steps = gut steps in the minute
     const int ns = nh >> 1;
-    const T h = T(1) / T(nh);                                     // glucose half step = gut step
-    const T H = h + h, H6 = H / T(6), hh = T(0.5) * h, h6 = h / T(6);
+    T h, H, H6, hh, h6;                                           // h: glucose half step = gut step
+    if (HC) {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        h = hc[z]; hh = hc[z + 1]; h6 = hc[z + 2]; H = hc[z + 3]; H6 = hc[z + 4];
+    } else {
+        h = T(1) / T(nh);
+        H = h + h; H6 = H / T(6); hh = T(0.5) * h; h6 = h / T(6);
+    }
     const T wE = r2 ? p(DP_X2E2) : p(DP_X2E), wA = r2 ? p(DP_X2WA2) : p(DP_X2WA);
     const T wM = r2 ? p(DP_X2WM2) : p(DP_X2WM), wB = r2 ? p(DP_X2WB2) : p(DP_X2WB);
     const T s5 = x[5], s6 = x[6], s7 = x[7], s8 = x[8], s9 = x[9], s10 = x[10], s11 = x[11], ui = u.ins;

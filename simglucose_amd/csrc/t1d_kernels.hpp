@@ -7,6 +7,9 @@
 //                      LDS, which the waves work off -- 64 at a time, every lane at level 2 -- once the queue is empty.
 //   step1_kernel       the same launch with every lane integrated in place: the fixed-step form (level 1 everywhere),
 //                      tables of more than 32 patients, batches whose list would not fit in LDS.
+//   stepn_kernel       a step of several minutes (sample_time > 1) or one closed-loop step with the controller fused, in
+//                      the same persistent form: the state stays in registers across the minutes, a lane that the rule
+//                      puts at level 2 is parked in LDS with its state and finished by the pass over the parked lanes.
 //   step_kernel        one launch per env.step, any minutes / layout / integrator: pump -> [meal bookkeeping ->
 //                      integration -> Gsub -> CGM sample/hold] x minutes -> risk/reward/done. (env.py:48-117)
 //   refill_kernel      rebuilds due 150-minute CGM noise blocks ahead of a step kernel compiled without that code.
@@ -34,6 +37,7 @@
 
 #include <climits>
 #include <cstdint>
+#include <type_traits>
 
 namespace t1d {
 
@@ -53,7 +57,6 @@ template <typename T> struct KArgs {
     long long* trace;       // T1D_S1_TRACE builds only: phase timestamps of the first blocks' waves
     SensorC<T> sen; PumpC<T> pump;
     int np, S, n_meals, n_normals, minutes, n_sub, flags, prop_rows, np_pad;
-    int sub;                // single-minute kernels: which minute of a `minutes`-minute step this launch is (0 .. minutes - 1)
 };
 
 template <typename T> struct PidArgs {
@@ -334,8 +337,8 @@ __device__ __forceinline__ T measure_apply(const KArgs<T>& a, Env<T>& e, T gsub,
 // With the `next_meal` state array the common minute costs no table access at all: the minute of the
 // next entry travels with the env state and the table is touched only when a meal fires.
 // HAS_NEXT: the caller knows that the next_meal array exists (packed layout)
-template <typename T, bool HAS_NEXT = false>
-__device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, Env<T>& e)
+template <typename T, bool HAS_NEXT = false, typename E = Env<T>>
+__device__ __forceinline__ T meal_lookup(const KArgs<T>& a, unsigned i, E& e)
 {
     T meal = T(0);
     if (HAS_NEXT || a.next_meal) {
@@ -549,7 +552,6 @@ __device__ __forceinline__ S1In<T> s1_load(const KArgs<T>& a, unsigned i)
     return in;
 }
 
-// MULTI: the launch is one minute of a step of several (t1d_step's minute_launches); otherwise a.minutes == 1, a.sub == 0
 // What s1_load fetched, kept in LDS for the listed envs (step1d_kernel): pt = [18][kS1DPark] of T, pi = [3][kS1DPark] ints
 constexpr int kS1DPark = 128;                                  // listed envs per CU whose inputs wait in LDS (a multiple of 64)
 template <typename T>
@@ -573,7 +575,7 @@ __device__ __forceinline__ S1In<T> s1_unpark(const T* pt, const int* pi, int slo
     return in;
 }
 
-template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, bool MULTI, typename ONLEVEL>
+template <bool REG, typename T, int STRIDE, bool EXTRA, int MODE, typename ONLEVEL>
 __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* lconst, unsigned i, const S1In<T>& in,
                                          ONLEVEL&& on_level, long long* tr, int tk)
 {
@@ -636,19 +638,9 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
         if (meta1 != meta) at(I(1), i) = (int32_t)meta1;
     }
-    // A step of several minutes (sample_time > 1) as one launch per minute: the outputs are the means over the step's
-    // minutes (env.py:78-81), summed up in the output arrays in the order step_kernel sums them in registers; reward,
-    // done and the risk indices follow in the step's last minute.
-    const bool sub_first = !MULTI || a.sub == 0, sub_last = !MULTI || a.sub == a.minutes - 1;
-    const T inv_div = MULTI ? T(1) / T(a.minutes) : T(1);
     if (EXTRA) {
-        if (!MULTI) {
-            if (a.meal) at(a.meal, i) = meal;
-            if (a.insulin) at(a.insulin, i) = insulin;
-        } else {
-            if (a.meal) at(a.meal, i) = (sub_first ? T(0) : (T)at(a.meal, i)) + meal * inv_div;
-            if (a.insulin) at(a.insulin, i) = (sub_first ? T(0) : (T)at(a.insulin, i)) + insulin * inv_div;
-        }
+        if (a.meal) at(a.meal, i) = meal;
+        if (a.insulin) at(a.insulin, i) = insulin;
     }
     S1_MARK(2);
 #if T1D_S1_PHASE_PRIO
@@ -681,9 +673,7 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
     for (int k = 0; k < 4; ++k) e.cur[k] = at(X(40 + k), i);
     // with a 1-minute sensor every minute takes a fresh sample: the held value is never read
     T last_cgm = a.sen.st == 1 ? T(0) : (T)at(X(16), i);
-    const T rp = sub_last ? (T)at(X(17), i) : T(0);           // risk index of the previous step's CGM
-    T bg_sum = T(0), cgm_sum = T(0);
-    if (!sub_first) { bg_sum = at(a.bg, i); cgm_sum = at(a.cgm, i); }
+    const T rp = at(X(17), i);                                // risk index of the previous step's CGM
     S1_MARK(4);
     bool due, entered = false;
     const T noise = measure_noise<false>(a, i, e, due, &entered);       // e.t is still the minute's start: sample for t + 1
@@ -702,13 +692,9 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         last_cgm = c;
         if (a.sen.st != 1) at(X(16), i) = c;                  // the zero-order hold is dead state with a 1-minute sensor
     }
-    T cgm_out = last_cgm, bg_out = gsub;
-    if (MULTI) {                                                                               // env.py:78-81
-        cgm_out = cgm_sum + last_cgm * inv_div; bg_out = bg_sum + gsub * inv_div;
-    }
+    const T cgm_out = last_cgm, bg_out = gsub;
     at(a.cgm, i) = cgm_out; at(a.bg, i) = bg_out;
     if (!(fabs((double)e.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
-    if (!sub_last) return;
     T l, h, r, rc = T(0);
     if (!ab_flag(a, 0x100)) risk_index1<1>(cgm_out, l, h, rc);
     at(a.reward, i) = rp - rc;                                                                 // env.py:27-33
@@ -748,7 +734,7 @@ __device__ __forceinline__ void s1_stage_tables(const KArgs<T>& a, T* ldp, T* lp
 }
 
 // every lane in place: TIERED = step sizes by the rule (LDS parameters), else level 1 everywhere (VGPR parameters)
-template <typename T, int STRIDE, bool EXTRA, bool TIERED, bool MULTI = false>
+template <typename T, int STRIDE, bool EXTRA, bool TIERED>
 __global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T> a, int nchunks)
 {
     // packed state only (t1d_step checks): rows 13.. of the x buffer are planned, last_qsto, last_food, last_cgm,
@@ -784,7 +770,7 @@ __global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T
         __builtin_assume(i < (1u << 28));
         ++tk;
         // (no `continue` for the lanes beyond the batch: they have to stay with their wave for the next draw)
-        if ((int64_t)i < a.n) s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0, MULTI>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), tr, tk);
+        if ((int64_t)i < a.n) s1_chunk<!TIERED, T, STRIDE, EXTRA, TIERED ? 1 : 0>(a, ldp, lpr, lconst, i, s1_load(a, i), S1NoLevel(), tr, tk);
     }
 }
 
@@ -805,7 +791,7 @@ __global__ __launch_bounds__(s1_threads<T>(), 1) void step1_kernel(const KArgs<T
 // chunk's loads issued ahead of the integration: 88 us against 83.)
 // The list pass too takes its parameters from VGPRs: it ends the launch alone on its SIMDs, where LDS round trips in the
 // dependent chains count.
-template <typename T, bool EXTRA, bool MULTI = false>
+template <typename T, bool EXTRA>
 __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs<T> a, int nchunks)
 {
     constexpr int STRIDE = 32;
@@ -865,7 +851,7 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
             tr = ph ? ph + 16 : nullptr;                    // per-chunk phase marks of the wave's first six chunks
 #endif
             const S1In<T> in = s1_load(a, i);
-            s1_chunk<true, T, STRIDE, EXTRA, 2, MULTI>(a, ldp, lpr, lconst, i, in, on_level(i, in), tr, it);
+            s1_chunk<true, T, STRIDE, EXTRA, 2>(a, ldp, lpr, lconst, i, in, on_level(i, in), tr, it);
         }
     }
     tr = nullptr;
@@ -887,13 +873,449 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
             __builtin_assume(i < (1u << 28));
             // (wave-uniform: a group of 64 entries lies inside the parked range or beyond it)
             const S1In<T> in = lo + 64 <= kS1DPark ? s1_unpark<T>(park_t, park_i, lo + (int)lane) : s1_load(a, i);
-            s1_chunk<true, T, STRIDE, EXTRA, 3, MULTI>(a, ldp, lpr, lconst, i, in, S1NoLevel(), nullptr, 0);
+            s1_chunk<true, T, STRIDE, EXTRA, 3>(a, ldp, lpr, lconst, i, in, S1NoLevel(), nullptr, 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
     S1D_PHASE(3);
     S1D_PHASE(4);
 #undef S1D_PHASE
+}
+
+// ---- a step of several minutes: state in registers across the minutes, lanes of level 2 set aside -----------------------
+// The reference's gym entry point runs Dexcom (sample_time 3, envs/simglucose_gym_env.py:24) and T1DSimEnv.step loops
+// int(sample_time) mini-steps under one action (simulation/env.py:75-81): one launch per env.step here too.  One persistent
+// workgroup per CU, tables in LDS, as step1d_kernel; the waves of a CU work off WORK ITEMS of up to 64 lanes:
+//   a chunk     64 consecutive envs from the CU's queue: loaded once, then `minutes` x [meal -> bookkeeping -> rule ->
+//               level-1 integration -> Gsub -> sample/hold] with the state in registers, then the step's epilogue;
+//   a record    whenever the rule puts a lane at level 2 the lane leaves its state AS IT STOOD AT THE START OF THAT MINUTE
+//               (x, bookkeeping, clock, the means so far, the minute's index) in a record in LDS and is done with the item;
+//               the rest of its wave carries on at level 1.  A wave that finds the queue empty takes up to 64 records --
+//               as soon as there is one -- and finishes those lanes' steps: each lane from its own minute, every lane at
+//               its own level in place (LDS parameters; a wave runs a minute at the level of its most refined lane).
+// So the chunks -- 99 % of the env-minutes -- run at level 1 with the state updated in place (a lane of a chunk runs every
+// minute or leaves for good: one that sat a minute out and came back would make the compiler keep a second copy of the
+// state across the sub-step loops), the records are worked off beside the last chunks, not behind them, and a batch of a
+// few chunks per CU has the latency of the in-place kernel.
+//   redo        a flagged lane that finds no record free leaves nothing but a bit in a map of the CU's envs (nothing of the
+//               item has been stored: the epilogue is where stores happen); once everything else is done the waves go
+//               through the map and take those envs again from their loads, like records.  Rare (a batch whose envs all
+//               start meals in the same minute); `mode` bit 2 sends every env there (tests).
+// CTRL: one closed-loop step per launch -- the controller (PIDController.policy, pid_ctrller.py:17-36, or BBController,
+// basal_bolus_ctrller.py:64-79) in the chunk's prologue, its state, statistics and history rows in the epilogue;
+// t1d_rollout_* makes one such launch per step for large batches (SimObj.simulate, sim_engine.py:29-39).
+template <typename T> struct SnLane {
+    T x[13];
+    T planned, lq, lf, insulin, bg_sum, cgm_sum, meal_sum, last_cgm;
+    int t, next_meal, cursor, m;
+    unsigned i;
+    uint32_t pid;
+    int dirty;          // 1: meal words changed, 2: next_meal changed, 4: eating flag / meal cursor changed
+    bool eating;
+};
+constexpr int kSnParkT = 21, kSnParkI = 5;           // words of a record: 21 of T, 5 ints
+constexpr int kSnDirtyShift = 9;                     // the three dirty bits ride in bits 9-11 of the record's meta word
+constexpr int kSnConst = 20;                         // lconst: pump 0-5, sensor limits 6-7, step sizes of level 1 8-12, of level 2 13-17
+constexpr int kSnSpinLimit = 1 << 20;                // polls before a waiting wave gives up and raises T1D_ST_STALL (never, by design)
+
+// the record's minute word doubles as its "written" flag: -1 until the lane that owns the slot has stored everything else
+template <typename T>
+__device__ __forceinline__ void sn_park(const SnLane<T>& L, T* pt, int* pi, int cap, int slot)
+{
+#pragma unroll
+    for (int k = 0; k < 13; ++k) pt[k * cap + slot] = L.x[k];
+    pt[13 * cap + slot] = L.planned; pt[14 * cap + slot] = L.lq; pt[15 * cap + slot] = L.lf; pt[16 * cap + slot] = L.insulin;
+    pt[17 * cap + slot] = L.bg_sum; pt[18 * cap + slot] = L.cgm_sum; pt[19 * cap + slot] = L.meal_sum; pt[20 * cap + slot] = L.last_cgm;
+    pi[slot] = (int)L.i; pi[cap + slot] = L.t; pi[2 * cap + slot] = L.next_meal;
+    pi[3 * cap + slot] = (int)(L.pid | (L.eating ? T1D_META_EATING : 0u) | ((uint32_t)L.dirty << kSnDirtyShift) | ((uint32_t)L.cursor << 16));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(&pi[4 * cap + slot], L.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the wave that has claimed records [lo, lo + n) waits until their owners have written them: every lane polls its record's
+// flag and the wave leaves together (a wave-uniform loop: no lane spins on its own)
+__device__ __forceinline__ void sn_wait_records(int* pi, int cap, int lo, int n, unsigned lane, int* status)
+{
+    for (int spins = 0;; ++spins) {
+        int m = 0;
+        if ((int)lane < n) m = __hip_atomic_load(&pi[4 * cap + lo + (int)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_ballot_w64(m < 0) == 0ull) break;
+        if (spins > kSnSpinLimit) { if (lane == 0) atomicOr(status, T1D_ST_STALL); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <typename T>
+__device__ __forceinline__ void sn_unpark(SnLane<T>& L, const T* pt, const int* pi, int cap, int slot)
+{
+#pragma unroll
+    for (int k = 0; k < 13; ++k) L.x[k] = pt[k * cap + slot];
+    L.planned = pt[13 * cap + slot]; L.lq = pt[14 * cap + slot]; L.lf = pt[15 * cap + slot]; L.insulin = pt[16 * cap + slot];
+    L.bg_sum = pt[17 * cap + slot]; L.cgm_sum = pt[18 * cap + slot]; L.meal_sum = pt[19 * cap + slot]; L.last_cgm = pt[20 * cap + slot];
+    L.i = (unsigned)pi[slot]; L.t = pi[cap + slot]; L.next_meal = pi[2 * cap + slot]; L.m = pi[4 * cap + slot];
+    const uint32_t w = (uint32_t)pi[3 * cap + slot];
+    L.pid = T1D_META_PID(w); L.eating = (w & T1D_META_EATING) != 0; L.dirty = (int)((w >> kSnDirtyShift) & 7u); L.cursor = (int)T1D_META_CURSOR(w);
+    if (L.m < 0) L.m = 1 << 30;                             // a record that never arrived (T1D_ST_STALL is up): nothing to run
+}
+
+// Two waves per SIMD in fp64: this kernel is bound by arithmetic, not by memory latency (three minutes of integration per
+// byte moved), and the fp64 pipe is as full with two waves as with three (tools/ubench/fp64_issue.hip: 5.4 against 5.2
+// cycles per v_fma_f64); with 256 registers per lane nothing spills in the minute loop.  (Three waves, 168 registers: 43
+// scratch accesses per lane and minute, 31 with the lane's eight idle words set down in LDS across the integration --
+// measured slower.)  fp32: four.
+#ifndef T1D_SN_WAVES
+#define T1D_SN_WAVES 2
+#endif
+#ifndef T1D_SN_WAVES_F32
+#define T1D_SN_WAVES_F32 4
+#endif
+template <typename T> constexpr int sn_threads() { return 256 * (sizeof(T) == 4 ? T1D_SN_WAVES_F32 : T1D_SN_WAVES); }
+// mode bit 1: step sizes by the rule (else level 1 in every minute); bit 2: every env through the redo pass (in place)
+template <typename T, bool EXTRA, bool CTRL>
+__global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T> a, const PidArgs<T> c, int nchunks, int park_cap, int mode)
+{
+    constexpr int STRIDE = 32;
+    constexpr int NT = sn_threads<T>();
+    T* const ldp = (T*)t1d_dyn_lds;                        // [DP_COUNT][STRIDE]
+    T* const lpr = ldp + DP_COUNT * STRIDE;                // [prop_rows][STRIDE]
+    T* const park_t = lpr + a.prop_rows * STRIDE;          // [kSnParkT][park_cap]
+    int* const park_i = (int*)(park_t + kSnParkT * park_cap);      // [kSnParkI][park_cap]
+    const int per_block = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
+    unsigned long long* const redo = (unsigned long long*)(park_i + kSnParkI * park_cap + ((kSnParkI * park_cap) & 1));   // [per_block]: envs to take again
+    __shared__ int queue, taken, parked, passed, redo_any, redo_next;
+    __shared__ T lconst[kSnConst];
+    s1_stage_tables<T, STRIDE>(a, ldp, lpr, lconst);
+    const int first = (int)blockIdx.x * per_block;
+    const int count = nchunks - first < per_block ? nchunks - first : per_block;
+    const bool tiered = (mode & 1) != 0, all_redo = (mode & 2) != 0;
+    if (threadIdx.x == 0) {
+        queue = 0; taken = 0; parked = 0; passed = all_redo ? count : 0; redo_any = 0; redo_next = 0;
+        T hc[5];
+        split_step_sizes<T>(a.n_sub, hc);
+        for (int k = 0; k < 5; ++k) lconst[8 + k] = hc[k];
+        split_step_sizes<T>(2 * a.n_sub, hc);
+        for (int k = 0; k < 5; ++k) lconst[13 + k] = hc[k];
+    }
+    for (int j = threadIdx.x; j < park_cap; j += NT) park_i[4 * park_cap + j] = -1;
+    for (int j = threadIdx.x; j < per_block; j += NT) {
+        unsigned long long bits = 0ull;
+        if (all_redo && j < count) {                        // every env of the chunk that exists
+            const int64_t left = a.n - (int64_t)(first + j) * 64;
+            bits = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+        }
+        redo[j] = bits;
+    }
+    if (threadIdx.x == 0 && all_redo) redo_any = 1;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u;
+    const BRows<T> X(a.x, a.n, kPackedRows);                // rows 0-12 x, 13 planned, 14 last_qsto, 15 last_food, 16 last_cgm, 17 prev_risk, 18.. pts
+    const BRows<int32_t> I(a.t, a.n, 3);                    // rows t, meta, next_meal
+    const T inv_div = T(1) / T(a.minutes);
+    const int st = a.sen.st;
+    // ---- the pieces of an item
+    // a chunk's loads, the controller (CTRL), the pump (env.py:51-52)
+    auto load_lane = [&](SnLane<T>& L, unsigned i) {
+        // what the pump and the first minute's bookkeeping need is requested first (loads return in order)
+        const uint32_t meta = (uint32_t)(int32_t)at(I(1), i);
+        L.t = at(I(0), i);
+        L.next_meal = at(I(2), i);
+        T basal = T(0), bolus = T(0);
+        bool has_bolus = a.bolus != nullptr;
+        T obs = T(0), k_integ = T(0), k_prev = T(0), bb_basal = T(0), bb_cr = T(1), bb_cf = T(1), prev_meal = T(0);
+        if (CTRL) {
+            obs = at(a.cgm, i);
+            if (c.kind == 1) { bb_basal = at(c.bb_basal, i); bb_cr = at(c.bb_cr, i); bb_cf = at(c.bb_cf, i); prev_meal = at(c.bb_prev_meal, i); }
+            else { k_integ = at(c.integ, i); k_prev = at(c.prev, i); }
+        } else {
+            basal = at(a.basal, i);
+            if (has_bolus) bolus = at(a.bolus, i);
+        }
+        L.planned = at(X(13), i); L.lq = at(X(14), i); L.lf = at(X(15), i);
+#pragma unroll
+        for (int k = 0; k < 13; ++k) L.x[k] = at(X(k), i);
+        L.last_cgm = st == 1 ? T(0) : (T)at(X(16), i);       // with a 1-minute sensor the held value is never read
+        L.i = i; L.m = 0; L.dirty = 0;
+        L.pid = T1D_META_PID(meta);
+        L.eating = (meta & T1D_META_EATING) != 0;
+        L.cursor = (int)T1D_META_CURSOR(meta);
+        if (CTRL) {
+            const T stT = T(st);
+            has_bolus = true;
+            if (c.kind == 1) {                              // BBController._bb_policy (basal_bolus_ctrller.py:64-79)
+                basal = bb_basal;
+                if (prev_meal > T(0)) {
+                    const T corr = obs > T(150) ? (obs - c.target) / bb_cf : T(0);
+                    bolus = ((prev_meal * stT) / bb_cr + corr) / stT;
+                }
+            } else {                                        // PIDController.policy (pid_ctrller.py:17-36); its state moves on in the epilogue
+                basal = c.P * (obs - c.target) + c.I * k_integ + c.D * (obs - k_prev) / stT;
+            }
+        }
+        T q_basal, q_bolus;
+        if (a.flags & T1D_BATCH_NO_PUMP) {
+            q_basal = basal; q_bolus = has_bolus ? bolus : T(0);
+        } else {
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const T* lc = lconst + z;
+            q_basal = pump_quantise(basal, lc[0], lc[1], lc[2]);                               // env.py:51
+            q_bolus = lc[4] > T(0) ? lc[4] : T(0);
+            if (has_bolus) q_bolus = pump_quantise(bolus, lc[3], lc[4], lc[5]);                // env.py:52
+        }
+        L.insulin = q_basal + q_bolus;
+        L.bg_sum = T(0); L.cgm_sum = T(0); L.meal_sum = T(0);
+    };
+    // scenario meal (env.py:50) -> meal bookkeeping (t1dpatient.py:82-107) -> the first gastric-emptying flux and the rule
+    auto minute_head = [&](SnLane<T>& L, T& meal, TierPre<T>& tp) -> MinuteIn<T> {
+        if (a.cho) {
+            meal = at(rowv(a.cho, a.n, L.m), L.i);
+            asm volatile("" : "+v"(meal));
+        } else {
+            meal = meal_lookup<T, true>(a, L.i, L);
+        }
+        ParsLdsS<T, STRIDE> pl{ldp, (int)L.pid};
+        MinuteIn<T> u = eat_minute<1, T>(pl, L.x, meal, L.insulin, L.planned, L.lq, L.lf, L.eating);
+        if (tiered) tp = tier_pre(pl, u, L.x);
+        else { tp.f1 = kgut_flux(pl, u, L.x[0], L.x[1]); tp.level2 = false; }
+        return u;
+    };
+    // one minute at a compile-time level: parameters gathered into registers for the sub-step loops, step sizes from LDS
+    auto integrate = [&](auto level, SnLane<T>& L, const MinuteIn<T>& u, T f1) {
+        constexpr int LEVEL = decltype(level)::value;
+        ParsLdsS<T, STRIDE> pl{ldp, (int)L.pid};
+        PropLdsS<T, STRIDE> pr{lpr, (int)L.pid};
+        ParsReg<T> p;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p.v[kSplitW(LEVEL) + k] = pl(kSplitW(LEVEL) + k);
+        p.pin_split();
+        split_level<LEVEL, T, ParsReg<T>, decltype(pr), true, true>(p, pr, u, L.x, a.n_sub, f1, false, lconst + (LEVEL == 1 ? 8 : 13));
+    };
+    // clock, Gsub (t1dpatient.py:217-218), the CGM sample if one is due (cgm.py:26-36), the step's means (env.py:78-81)
+    auto minute_tail = [&](SnLane<T>& L, T meal) {
+        L.t += 1;
+        ParsLdsS<T, STRIDE> pl{ldp, (int)L.pid};
+        const T gsub = L.x[12] * pl(DP_IVG);
+        int q, r;
+        divmod_uniform(L.t, st, q, r);
+        if (r == 0) {
+            T cur[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = at(X(40 + k), L.i);
+            bool entered = false;
+            const T noise = noise_sample<false>(a, L.i, 1 + q, cur, &entered);
+            if (entered) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) at(X(40 + k), L.i) = cur[k];
+            }
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const T vmin = lconst[6 + z], vmax = lconst[7 + z];
+            T cv = gsub + noise;
+            cv = cv > vmin ? cv : vmin;
+            cv = cv < vmax ? cv : vmax;
+            L.last_cgm = cv;
+        }
+        L.meal_sum += meal * inv_div; L.bg_sum += gsub * inv_div; L.cgm_sum += L.last_cgm * inv_div;
+    };
+    // the step's epilogue (env.py:85-117) and the state's way back
+    auto epilogue = [&](SnLane<T>& L) {
+        const unsigned i = L.i;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) at(X(k), i) = L.x[k];
+        if (L.dirty & 1) { at(X(13), i) = L.planned; at(X(14), i) = L.lq; at(X(15), i) = L.lf; }
+        at(I(0), i) = L.t;
+        if (L.dirty & 2) at(I(2), i) = L.next_meal;
+        if (L.dirty & 4) at(I(1), i) = (int32_t)(L.pid | (L.eating ? T1D_META_EATING : 0u) | ((uint32_t)L.cursor << 16));
+        if (st != 1) at(X(16), i) = L.last_cgm;
+        const T rp = at(X(17), i);                          // risk index of the previous step's CGM
+        const T cgm_out = L.cgm_sum, bg_out = L.bg_sum;
+        if (CTRL && c.kind == 0) {                          // pid_ctrller.py:30-33: the observation the policy acted on is still in place
+            const T obs = at(a.cgm, i);
+            at(c.integ, i) = (T)at(c.integ, i) + (obs - c.target) * T(st);
+            at(c.prev, i) = obs;
+        }
+        at(a.cgm, i) = cgm_out; at(a.bg, i) = bg_out;
+        if (!(fabs((double)L.x[12]) <= 1.0e300)) atomicOr(a.status, T1D_ST_NONFINITE);
+        T l, h, r = T(0), rc = T(0);
+        risk_index1<1>(cgm_out, l, h, rc);
+        at(a.reward, i) = rp - rc;                                                             // env.py:27-33
+        at(X(17), i) = rc;
+        at(a.done, i) = (bg_out < T(70) || bg_out > T(350)) ? 1 : 0;                           // env.py:103
+        T ins_out = L.insulin;
+        if (a.minutes != 1) {                               // the mean as env.py:79 accumulates it
+            ins_out = T(0);
+            for (int m = 0; m < a.minutes; ++m) ins_out += L.insulin * inv_div;
+        }
+        if (EXTRA) {
+            const bool want_risk = a.lbgi || a.hbgi || a.risk || (CTRL && c.sum_risk);
+            if (want_risk) risk_index1<1>(bg_out, l, h, r);                                    // env.py:85
+            if (a.lbgi) at(a.lbgi, i) = l;
+            if (a.hbgi) at(a.hbgi, i) = h;
+            if (a.risk) at(a.risk, i) = r;
+            if (a.meal) at(a.meal, i) = L.meal_sum;
+            if (a.insulin) at(a.insulin, i) = ins_out;
+        }
+        if (CTRL) {
+            if (c.kind == 1) at(c.bb_prev_meal, i) = L.meal_sum;
+            if (c.bg_trace) c.bg_trace[c.trace_row * a.n + i] = bg_out;
+            if (c.cgm_trace) c.cgm_trace[c.trace_row * a.n + i] = cgm_out;
+            if (c.cho_trace) c.cho_trace[c.trace_row * a.n + i] = L.meal_sum;
+            if (c.ins_trace) c.ins_trace[c.trace_row * a.n + i] = ins_out;
+            if (c.sum_risk) at(c.sum_risk, i) = (T)at(c.sum_risk, i) + r;
+            if (c.min_bg) { const T v = at(c.min_bg, i); at(c.min_bg, i) = bg_out < v ? bg_out : v; }
+            if (c.max_bg) { const T v = at(c.max_bg, i); at(c.max_bg, i) = bg_out > v ? bg_out : v; }
+            if (c.n_low) at(c.n_low, i) = (int)at(c.n_low, i) + (bg_out < T(70) ? 1 : 0);
+            if (c.n_high) at(c.n_high, i) = (int)at(c.n_high, i) + (bg_out > T(180) ? 1 : 0);
+        }
+    };
+    for (;;) {
+        // ---- the next work item: a chunk while the queue lasts, else up to 64 records -- whatever is there: a wave with
+        // nothing else to do takes a single record too (the record's minutes then run beside the last chunks, not behind
+        // them) --, at the very end the words of the redo map
+        int w_chunk = -1, w_lo = 0, w_n = 0, w_redo = -1;
+        if (lane == 0) {
+            // a full wave's worth of records goes ahead of the next chunk: worked off in full waves while the chunks last,
+            // they leave only the stragglers for the end of the launch
+            bool full = false;
+            if (!all_redo) {
+                int pk = __hip_atomic_load(&parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pk = pk < park_cap ? pk : park_cap;
+                int tk = __hip_atomic_load(&taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pk - tk >= 64 && __hip_atomic_compare_exchange_strong(&taken, &tk, tk + 64, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    w_lo = tk; w_n = 64; full = true;
+                }
+            }
+            const int cc = (all_redo || full) ? count : atomicAdd(&queue, 1);
+            if (cc < count) w_chunk = cc;
+            else if (!full) {
+                for (int spins = 0;; ++spins) {
+                    // `passed` first: once every chunk is past its last decision the record count is final
+                    const int ps = __hip_atomic_load(&passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    int pk = __hip_atomic_load(&parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pk = pk < park_cap ? pk : park_cap;
+                    int tk = __hip_atomic_load(&taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int avail = pk - tk;
+                    if (avail > 0) {
+                        const int n = avail < 64 ? avail : 64;
+                        if (__hip_atomic_compare_exchange_strong(&taken, &tk, tk + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            w_lo = tk; w_n = n;
+                            break;
+                        }
+                        continue;
+                    }
+                    if (ps >= count) {
+                        // no record left and no chunk that could still leave one: what remains is the redo map, final now
+                        if (__hip_atomic_load(&redo_any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            const int rw = atomicAdd(&redo_next, 1);
+                            if (rw < count) w_redo = rw;
+                        }
+                        break;
+                    }
+                    if (spins > kSnSpinLimit) { atomicOr(a.status, T1D_ST_STALL); break; }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+        }
+        w_chunk = __builtin_amdgcn_readfirstlane(w_chunk);
+        w_lo = __builtin_amdgcn_readfirstlane(w_lo);
+        w_n = __builtin_amdgcn_readfirstlane(w_n);
+        w_redo = __builtin_amdgcn_readfirstlane(w_redo);
+        if (w_chunk < 0 && w_n == 0 && w_redo < 0) break;   // wave-uniform
+#if T1D_S1_PHASE_PRIO
+        __builtin_amdgcn_s_setprio(T1D_S1_PHASE_PRIO);
+#endif
+        if (w_chunk < 0) {
+            // ---- records: each lane from the minute it was parked in (which the rule, on the same state, puts at level 2
+            // again); a word of the redo map: the envs of a chunk that found no record free, from their loads.  Every lane
+            // at its own level, in place.
+            SnLane<T> L;
+            bool active;
+            if (w_n > 0) {
+                sn_wait_records(park_i, park_cap, w_lo, w_n, lane, a.status);
+                active = (int)lane < w_n;
+                if (active) { sn_unpark(L, park_t, park_i, park_cap, w_lo + (int)lane); }
+            } else {
+                const unsigned i = (unsigned)(first + w_redo) * 64u + lane;
+                __builtin_assume(i < (1u << 28));
+                active = ((redo[w_redo] >> lane) & 1ull) != 0ull;
+                if (active) load_lane(L, i);
+            }
+            for (;;) {
+                const bool on = active && L.m < a.minutes;
+                if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;             // wave-uniform
+                if (on) {
+                    T meal = T(0);
+                    TierPre<T> tp{T(0), false};
+                    const T planned0 = L.planned, lq0 = L.lq, lf0 = L.lf;
+                    const int nm0 = L.next_meal, cur0 = L.cursor;
+                    const bool eat0 = L.eating;
+                    const MinuteIn<T> u = minute_head(L, meal, tp);
+                    L.dirty |= ((L.planned != planned0 || L.lq != lq0 || L.lf != lf0) ? 1 : 0) | (L.next_meal != nm0 ? 2 : 0) |
+                               ((L.cursor != cur0 || L.eating != eat0) ? 4 : 0);
+                    ParsLdsS<T, STRIDE> pl{ldp, (int)L.pid};
+                    PropLdsS<T, STRIDE> pr{lpr, (int)L.pid};
+                    split_level<0, T, ParsLdsS<T, STRIDE>, decltype(pr), true>(pl, pr, u, L.x, a.n_sub, tp.f1, tp.level2);
+                    minute_tail(L, meal);
+                    L.m += 1;
+                }
+            }
+            if (active) { epilogue(L); }
+            continue;
+        }
+        // ---- a chunk
+        const unsigned i0 = (unsigned)(first + w_chunk) * 64u + lane;
+        __builtin_assume(i0 < (1u << 28));
+        bool left = true;                                   // lanes beyond the batch have nothing to finish
+        SnLane<T> L;
+        if ((int64_t)i0 < a.n) {
+            load_lane(L, i0);
+            left = false;
+            while (L.m < a.minutes) {
+                T meal = T(0);
+                TierPre<T> tp{T(0), false};
+                // the lane as it stands at the start of the minute: what a record holds
+                const T planned0 = L.planned, lq0 = L.lq, lf0 = L.lf;
+                const int nm0 = L.next_meal, cur0 = L.cursor;
+                const bool eat0 = L.eating;
+                const MinuteIn<T> u = minute_head(L, meal, tp);
+                if (tp.level2) {
+                    // level 2: leave a record (or, no record free, a bit in the redo map) and be done with this item
+                    L.planned = planned0; L.lq = lq0; L.lf = lf0; L.next_meal = nm0; L.cursor = cur0; L.eating = eat0;
+                    const int slot = atomicAdd(&parked, 1);
+                   
+                    if (slot < park_cap) sn_park(L, park_t, park_i, park_cap, slot);
+                    else {
+                       
+                        const unsigned rel = L.i - (unsigned)first * 64u;
+                        atomicOr(&redo[rel >> 6], 1ull << (rel & 63u));
+                        redo_any = 1;
+                    }
+                    left = true;
+                    break;
+                }
+                L.dirty |= ((L.planned != planned0 || L.lq != lq0 || L.lf != lf0) ? 1 : 0) | (L.next_meal != nm0 ? 2 : 0) |
+                           ((L.cursor != cur0 || L.eating != eat0) ? 4 : 0);
+#if T1D_S1_PHASE_PRIO
+                __builtin_amdgcn_s_setprio(0);              // the integration fills the issue slots the other phases leave
+#endif
+                integrate(std::integral_constant<int, 1>(), L, u, tp.f1);
+#if T1D_S1_PHASE_PRIO
+                __builtin_amdgcn_s_setprio(T1D_S1_PHASE_PRIO);
+#endif
+                minute_tail(L, meal);
+                L.m += 1;
+            }
+        }
+        // past this chunk's last decision: it can leave no more records.  (Lane 0 of a chunk is always a live env.  The
+        // count goes up BEFORE the epilogue, not as the loop body's last statement: a one-lane atomic right in front of
+        // the back edge came out of hipcc 7.2 with the other 63 lanes dropped from the next trip.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) atomicAdd(&passed, 1);
+        if (!left) { epilogue(L); }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
 }
 
 // Rebuilds the CGM noise block of every env whose next sample(s) -- in minutes (t, t + minutes] -- start a
@@ -1070,14 +1492,16 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs<T> a, const u
 // T1DPatient.model at n independent points (t1d_model_rhs): the RHS of the step kernels, on its own
 template <int MATH, typename T>
 __global__ __launch_bounds__(kBlock) void rhs_kernel(int64_t n, const T* x, const int32_t* pid, const T* cho, const T* ins,
-                                                     const T* lq, const T* lf, T* out, const T* dpar)
+                                                     const T* lq, const T* lf, T* out, const T* dpar, int np, int* status)
 {
     __shared__ T lds[DP_RK4_COUNT * kMaxPatients];
     for (int j = threadIdx.x; j < DP_RK4_COUNT * kMaxPatients; j += blockDim.x) lds[j] = dpar[j];
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    ParsLds<T> p{lds, pid[i]};
+    int row = pid[i];
+    if ((unsigned)row >= (unsigned)np) { atomicOr(status, T1D_ST_BAD_INDEX); row = 0; }      // never index the table out of range
+    ParsLds<T> p{lds, row};
     T xs[13], k[13];
 #pragma unroll
     for (int j = 0; j < 13; ++j) xs[j] = x[j * n + i];

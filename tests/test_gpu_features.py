@@ -392,6 +392,42 @@ def test_custom_patient_table_with_more_than_32_patients(sensor):
     assert e.sync() == 0
 
 
+@pytest.mark.parametrize("sensor,n_sub", [("Navigator", 4), ("Dexcom", 4), ("Navigator", 8), ("Dexcom", 8)])
+def test_table_of_64_patients_runs_at_every_substep_count(sensor, n_sub):
+    """The largest table the header allows (64 patients) at n_sub = 4 and 8: 133 / 245 propagator rows x 64 columns is
+    more than 64 KiB of LDS.  One-minute launches take the persistent kernel's 64-patient layout; steps of several minutes
+    take the generic kernel with its dynamic-LDS ceiling raised -- neither may refuse the call (integrator = -1 promises
+    the split scheme whenever math and n_sub allow it) and both follow the oracle on the same table."""
+    import torch
+    from simglucose_amd import params
+    from oracle import t1d_oracle as O
+    names, tab = params.patient_table()
+    rs = np.random.RandomState(64)
+    extra = tab[rs.randint(0, 30, 34)].copy()
+    for c in ("kabs", "kmax", "kp2", "k1", "k2", "m1", "m30", "ka2", "ksc", "p2u", "ki", "Vmx"):
+        extra[:, params.P_COL[c]] *= rs.uniform(0.9, 1.1, 34)
+    big = np.ascontiguousarray(np.vstack([tab, extra]))
+    n = 128
+    pid = np.arange(n) % 64
+    z = rs.randn(20, n)
+    e = _mk(patient=pid, patient_table=big, sensor=sensor, noise="host", normals=z, n_sub=n_sub)
+    orc = O.OracleEnv(pid, sensor=sensor, normals=z, integrator="split_adaptive", n_sub=n_sub, ptab_override=big)
+    o0, r0 = e.reset(), orc.reset()
+    assert np.abs(o0.cpu().numpy() - r0["cgm"]).max() < 1e-9
+    st = int(e.minutes_per_step)
+    b = big[pid, params.P_COL["u2ss"]] * big[pid, params.P_COL["BW"]] / 6000.0
+    for k in range(30):
+        cho = np.zeros((st, n))
+        if k == 3:
+            cho[0] = 60.0
+        a = b * (0.4 + 0.4 * (k % 4))
+        e.step(torch.as_tensor(a, device=e.device), cho=cho)
+        r = orc.step(a, None, cho)
+        assert np.abs(e.bg.cpu().numpy() - r["bg"]).max() < 1e-8, k
+        assert np.abs(e.cgm.cpu().numpy() - r["cgm"]).max() < 1e-8, k
+    assert e.sync() == 0
+
+
 @pytest.mark.parametrize("pump", ["Insulet", "Cozmo"])
 @pytest.mark.parametrize("sensor", ["Navigator", "Dexcom"])
 def test_pump_quantiser_in_kernel_matches_reference(golden, pump, sensor):
@@ -606,6 +642,62 @@ def test_state_dict_roundtrip_and_determinism():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_clock_edited_behind_the_wrapper_still_refills_noise_blocks():
+    """The wrapper shadows a lock-step clock on the host to skip the noise-block refill pre-kernel.  A caller who moves
+    env.t in place (instead of going through load_state_dict) must not get a stale noise block: the edit is noticed
+    (version counter of the state tensors) and the envs' own clocks decide again.  Reference run: the same jump through
+    state_dict / load_state_dict; the jump lands 4 minutes before a block boundary."""
+    import torch
+    n = 256
+    pid = np.arange(n) % 30
+    envs = [_mk(patient=pid, sensor="Navigator", noise="philox", seed=31, n_sub=4) for _ in range(2)]
+    b = torch.as_tensor(_basal(pid), device="cuda:0")
+    for e in envs:
+        e.reset()
+        for _ in range(100):
+            e.step(b)
+    assert envs[0]._clock == 100
+    envs[0].t += 45                                   # behind the wrapper's back: sample #150 (a new block) is now 4 steps away
+    sd = envs[1].state_dict(); sd["t"] = sd["t"] + 45
+    envs[1].load_state_dict(sd)
+    assert isinstance(envs[0].info()["t"], torch.Tensor) and envs[0].info()["t"].data_ptr() != envs[0].t.data_ptr()
+    pts_before = envs[0].pts[:11].clone()
+    for _ in range(12):
+        envs[0].step(b); envs[1].step(b)
+    assert envs[0]._clock is None
+    assert not torch.equal(pts_before, envs[0].pts[:11])              # the block was rebuilt
+    assert torch.equal(envs[0].pts, envs[1].pts) and torch.equal(envs[0].cgm, envs[1].cgm) and torch.equal(envs[0].t, envs[1].t)
+    assert envs[0].sync() == 0 and envs[1].sync() == 0
+
+
+def test_checkpoint_format_and_history_after_load():
+    """state_dict carries a format number (a checkpoint of another layout is refused, not half-loaded) and loading a
+    checkpoint without a CGM history into an env that keeps one re-seeds the ring from the restored observation."""
+    import torch
+    from simglucose_amd._lib import T1DError
+    n = 128
+    pid = np.arange(n) % 30
+    a = _mk(patient=pid, sensor="Dexcom", noise="philox", seed=2)
+    a.reset()
+    b0 = torch.as_tensor(_basal(pid), device=a.device)
+    for _ in range(5):
+        a.step(b0)
+    sd = a.state_dict()
+    assert sd["format"] == a.STATE_FORMAT
+    h = _mk(patient=pid, sensor="Dexcom", noise="philox", seed=2, cgm_history=True)
+    h.reset()
+    for _ in range(9):
+        h.step(1.3 * b0)
+    h.load_state_dict(sd)
+    w = h.cgm_window()
+    assert torch.equal(w[-1], a.cgm) and bool(torch.isnan(w[:-1]).all())
+    old = dict(sd); del old["format"]
+    with pytest.raises(T1DError):
+        h.load_state_dict(old)
+    with pytest.raises(ValueError):
+        h.model_rhs(torch.zeros(13, 2), [0, 99], [0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [0.0, 0.0])
+
+
 def test_full_batch_properties_1m_envs():
     """BASELINE.json's full size (1 048 576 envs): size-independent properties.  (1) every env of a
     patient-homogeneous batch with identical inputs carries identical state; (2) shifting the batch
@@ -698,22 +790,34 @@ def test_full_size_24h_run_sampled_envs_match_oracle(adaptive):
     assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K == int(e.t.max())
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("sensor,dtype_name", [("Dexcom", "f64"), ("GuardianRT", "f64"), ("Dexcom", "f32")])
-def test_multi_minute_step_as_one_launch_per_minute(sensor, dtype_name):
-    """A step of sample_time minutes taken as one single-minute launch per minute (what large batches do: the set-aside
-    form of the step-size rule) against the same step inside one launch of the generic kernel: same lanes refine, same
-    arithmetic, outputs summed in the same order -- meals from tables, extra outputs, 8 h."""
+@pytest.mark.parametrize("sensor,dtype_name,form", [("Dexcom", "f64", "default"), ("GuardianRT", "f64", "default"), ("Dexcom", "f32", "default"),
+                                                    ("Dexcom", "f64", "small_park"), ("Dexcom", "f64", "in_place"), ("Dexcom", "f64", "fixed"),
+                                                    ("GuardianRT", "f32", "small_park")])
+def test_multi_minute_kernel_equals_generic_kernel(sensor, dtype_name, form):
+    """A step of sample_time minutes in one launch of the persistent multi-minute kernel (state in registers across the
+    minutes, lanes of level 2 parked in LDS and finished by the pass over the records) against the same step inside one
+    launch of the generic kernel: the same lanes refine in the same minutes with the same arithmetic and the outputs are
+    summed in the same order -- meals from tables, extra outputs, 8 h.  Forms: the default record capacity; 64 records per
+    workgroup and a 3-block grid (most waves find no room and finish their chunks in place, the overflow path); every chunk
+    in place (adaptive_gut = 2); level 1 in every minute (adaptive_gut = 0).  Some envs share their meal plan so that whole
+    waves are flagged at once."""
     import torch
     from simglucose_amd import scenario_batch as sb
     dt = torch.float64 if dtype_name == "f64" else torch.float32
     n = 64 * 50 - 5
     pid = np.arange(n) % 30
     mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=7 * 60, seed=3, device="cuda:0", dtype=dt)
+    mt[:, :320] = mt[:, :1]; ma[:, :320] = ma[:, :1]        # five waves of envs with one meal plan
     envs = []
     for mode in (0, 2):
         e = _mk(patient=pid, sensor=sensor, dtype=dt, noise="philox", seed=9, n_sub=4, extra_outputs=True)
-        e.set_option("minute_launches", mode)
+        e.set_option("multi_minute_kernel", mode)
+        if form == "small_park":
+            e.set_option("park_cap", 64); e.set_option("s1_blocks", 3)
+        elif form == "in_place":
+            e.set_option("adaptive_gut", 2)
+        elif form == "fixed":
+            e.set_option("adaptive_gut", 0)
         e.set_meals(mt, ma)
         e.reset()
         envs.append(e)
@@ -722,12 +826,63 @@ def test_multi_minute_step_as_one_launch_per_minute(sensor, dtype_name):
     steps = 480 // int(envs[0].sample_time)
     for k in range(steps):
         a = b * (0.4 + 0.3 * (k % 5))
-        o0 = envs[0].step(a); o1 = envs[1].step(a)
+        envs[0].step(a); envs[1].step(a)
         if k % 20 == 19 or k == 0:
             for key in ("cgm", "bg", "reward", "risk", "lbgi", "hbgi", "meal", "insulin"):
                 assert float((getattr(envs[0], key) - getattr(envs[1], key)).abs().max()) < tol, (k, key)
             assert torch.equal(envs[0].done, envs[1].done)
     assert torch.equal(envs[0].t, envs[1].t) and int(envs[0].t[0]) == steps * int(envs[0].sample_time)
+    assert torch.equal(envs[0].meta, envs[1].meta) and torch.equal(envs[0].next_meal, envs[1].next_meal)
     assert float((envs[0].x - envs[1].x).abs().max()) < tol * 100
-    assert float((envs[0].prev_risk - envs[1].prev_risk).abs().max()) < tol
+    for key in ("prev_risk", "last_cgm", "planned", "last_qsto", "last_food"):
+        assert float((getattr(envs[0], key) - getattr(envs[1], key)).abs().max()) < tol, key
     assert envs[0].sync() == 0 and envs[1].sync() == 0
+
+
+@pytest.mark.parametrize("dtype_name,ctrl", [("f64", "pid"), ("f64", "bb"), ("f32", "pid")])
+def test_rollout_as_one_launch_per_step_equals_single_launch_rollout(dtype_name, ctrl):
+    """t1d_rollout_pid / t1d_rollout_bb as one launch of the multi-minute kernel per step (controller fused into the launch,
+    what large batches take) against all steps inside one launch of the generic roll-out kernel: states, controller state,
+    statistics and the device-resident histories agree -- 6 h of Dexcom steps in calls of different lengths."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    dt = torch.float64 if dtype_name == "f64" else torch.float32
+    n = 64 * 20 - 3
+    pid = np.arange(n) % 30
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=6 * 60, seed=21, device="cuda:0", dtype=dt)
+    res = []
+    for mode in (0, 2):
+        e = _mk(patient=pid, sensor="Dexcom", dtype=dt, noise="philox", seed=12, n_sub=4, extra_outputs=True)
+        e.set_option("rollout_launches", mode)
+        e.set_option("multi_minute_kernel", 2)
+        e.set_meals(mt, ma)
+        e.reset()
+        K = 120
+        tr = e.new_trace(K)
+        stats = {"sum_risk": torch.zeros(n, dtype=dt, device=e.device), "min_bg": torch.full((n,), 1e9, dtype=dt, device=e.device),
+                 "max_bg": torch.zeros(n, dtype=dt, device=e.device), "n_low": torch.zeros(n, dtype=torch.int32, device=e.device),
+                 "n_high": torch.zeros(n, dtype=torch.int32, device=e.device)}
+        st = None
+        for chunk in (1, 19, 100):
+            if ctrl == "pid":
+                st = e.rollout_pid(chunk, 1.5e-4, 4e-7, 5e-4, 140.0, pid_state=st, stats=stats, trace=tr)
+            else:
+                st = e.rollout_bb(chunk, bb_state=st, stats=stats, trace=tr)
+        assert e.sync() == 0
+        res.append((e, st, stats, tr))
+    (ea, sa, sta, tra), (eb, sb_, stb, trb) = res
+    tol = 1e-9 if dtype_name == "f64" else 5e-3
+    for k in ("x", "cgm", "bg", "last_cgm", "prev_risk", "reward", "planned", "last_qsto", "last_food", "meal", "insulin", "risk"):
+        assert float((getattr(ea, k).double() - getattr(eb, k).double()).abs().max()) < tol * (100 if k == "x" else 1), k
+    assert torch.equal(ea.t, eb.t) and torch.equal(ea.meta, eb.meta) and torch.equal(ea.done, eb.done)
+    for k in (("integ", "prev") if ctrl == "pid" else ("prev_meal",)):
+        assert float((sa[k].double() - sb_[k].double()).abs().max()) < tol * (1e4 if k == "integ" else 1), k
+    for k in ("bg", "cgm", "cho", "insulin"):
+        d = (tra[k].double() - trb[k].double()).abs()
+        assert float(d[torch.isfinite(d)].max()) < tol, k
+        assert torch.equal(torch.isnan(tra[k]), torch.isnan(trb[k])), k
+    for k in ("min_bg", "max_bg"):
+        assert float((sta[k].double() - stb[k].double()).abs().max()) < tol, k
+    assert float((sta["sum_risk"].double() - stb["sum_risk"].double()).abs().max()) < tol * 1e3
+    if dtype_name == "f64":
+        assert torch.equal(sta["n_low"], stb["n_low"]) and torch.equal(sta["n_high"], stb["n_high"])
