@@ -387,9 +387,9 @@ def main(argv=None):
     if rank == 0:
         tname = "double" if a.dtype == "f64" else "float"
         if integ != "rk4" and st == 1:
-            kernel_name = {"split": "void t1d::step1_kernel<%s, 32, false, false, false>(t1d::KArgs<%s>, int)",
-                           "split_adaptive": "void t1d::step1_kernel<%s, 32, false, true, false>(t1d::KArgs<%s>, int)" if a.in_place
-                                             else "void t1d::step1d_kernel<%s, false, false>(t1d::KArgs<%s>, int)"}[integ] % (tname, tname)
+            kernel_name = {"split": "void t1d::step1_kernel<%s, 32, false, false>(t1d::KArgs<%s>, int)",
+                           "split_adaptive": "void t1d::step1_kernel<%s, 32, false, true>(t1d::KArgs<%s>, int)" if a.in_place
+                                             else "void t1d::step1d_kernel<%s, false>(t1d::KArgs<%s>, int)"}[integ] % (tname, tname)
         else:
             kernel_name = "void t1d::step_kernel<%d, %s, false>(t1d::KArgs<%s>)" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname, tname)
         # last recorded PMC measurements of this exact configuration (tools/profile_bench.sh): HBM bytes, VALU instructions

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define T1D_ABI_VERSION 3
+#define T1D_ABI_VERSION 4
 
 enum { T1D_F64 = 0, T1D_F32 = 1 };
 
@@ -81,9 +81,11 @@ enum {
 #define T1D_PUMP_NCOLS 6
 
 /* per-env packed integer word `meta`: bits 0-7 patient row, bit 8 "was eating last minute"
- * (t1dpatient.py:88,102 edge detector), bits 16-31 cursor into the meal table. */
+ * (t1dpatient.py:88,102 edge detector), bit 9 "planned_meal > 0" (with bit 8: the three meal words are live -- while
+ * both are clear the next minute needs nothing of them but Dbar), bits 16-31 cursor into the meal table. */
 #define T1D_META_PID(m)      ((m) & 0xffu)
 #define T1D_META_EATING      0x100u
+#define T1D_META_PLANNED     0x200u
 #define T1D_META_CURSOR(m)   ((m) >> 16)
 
 /* t1d_batch.flags; any other bit is rejected with T1D_E_INVALID */
@@ -108,9 +110,10 @@ typedef struct t1d_batch {
     uint64_t seed;            /* Philox key */
     /* ---- state (read + written by t1d_step; written by t1d_reset).
      * PACKED layout (recommended; detected from the pointers): x, planned, last_qsto, last_food, last_cgm,
-     * prev_risk, pts are consecutive rows of ONE [44][n] buffer in that order, and t, meta, next_meal are
+     * prev_risk, pts, dbar are consecutive rows of ONE [45][n] buffer in that order, and t, meta, next_meal are
      * consecutive rows of one [3][n] int32 buffer.  With it one-minute launches (minutes == 1) take the
-     * persistent single-minute kernels; any other layout runs the generic step kernel. */
+     * persistent single-minute kernels and large fp64 batches the persistent multi-minute kernel; any other layout
+     * runs the generic step kernel. */
     void* x;                  /* [13][n] ODE state */
     void* planned;            /* [n] planned_meal, g        (t1dpatient.py:229) */
     void* last_qsto;          /* [n] mg                     (t1dpatient.py:90)  */
@@ -129,6 +132,11 @@ typedef struct t1d_batch {
                                  points, 11-21 their knot second derivatives, 22-25 the current 15-min interval */
     void* prev_risk;          /* [n] risk index of CGM_hist[-1]: the default reward risk_diff (env.py:27-33) is
                                * risk(CGM_hist[-2]) - risk(CGM_hist[-1]); its first term is the second term of the step before */
+    void* dbar;               /* [n] Dbar = last_qsto + last_food * 1000 (t1dpatient.py:130), kept beside the two words it is
+                               * made of: in the minutes in which an env neither eats nor has a meal planned (bits 8, 9 of
+                               * meta clear: ~95 %) the gastric-emptying term needs nothing else of the meal bookkeeping, and
+                               * the one-minute kernels then read this word instead of three.  Written by t1d_reset and by
+                               * every step that changes last_qsto / last_food.  NULL = not kept (never with the packed layout) */
     /* ---- inputs */
     const void* basal;        /* [n] U/min */
     const void* bolus;        /* [n] U/min, NULL = 0 */

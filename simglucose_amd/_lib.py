@@ -13,9 +13,10 @@ SOURCES = [os.path.join(_PKG, "csrc", "t1d_abi.hip"), os.path.join(_PKG, "csrc",
 
 T1D_F64, T1D_F32 = 0, 1
 T1D_ST_NORMALS_EXHAUSTED, T1D_ST_NONFINITE, T1D_ST_BAD_INDEX, T1D_ST_STALL = 1, 2, 4, 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 T1D_BATCH_NO_PUMP = 2
 T1D_BATCH_NO_REFILL_DUE = 4
+META_PLANNED = 0x200
 P_NCOLS = 45
 MEAL_UNUSED = 0x7FFFFFFF
 META_EATING = 0x100
@@ -36,7 +37,7 @@ class Batch(C.Structure):
         ("n_normals", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64),
         ("x", C.c_void_p), ("planned", C.c_void_p), ("last_qsto", C.c_void_p), ("last_food", C.c_void_p),
         ("t", C.c_void_p), ("meta", C.c_void_p), ("episode", C.c_void_p), ("next_meal", C.c_void_p),
-        ("last_cgm", C.c_void_p), ("ar_e", C.c_void_p), ("pts", C.c_void_p), ("prev_risk", C.c_void_p),
+        ("last_cgm", C.c_void_p), ("ar_e", C.c_void_p), ("pts", C.c_void_p), ("prev_risk", C.c_void_p), ("dbar", C.c_void_p),
         ("basal", C.c_void_p), ("bolus", C.c_void_p), ("cho", C.c_void_p), ("meal_time", C.c_void_p),
         ("meal_amt", C.c_void_p), ("normals", C.c_void_p), ("x0_override", C.c_void_p),
         ("cgm", C.c_void_p), ("bg", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),

@@ -15,7 +15,7 @@ import torch
 from . import _lib, params
 
 _STATE_KEYS = ("x", "planned", "last_qsto", "last_food", "t", "meta", "episode", "next_meal", "last_cgm", "ar_e",
-               "pts", "prev_risk")
+               "pts", "prev_risk", "dbar")
 _OUT_KEYS = ("cgm", "bg", "reward", "done", "lbgi", "hbgi", "risk", "meal", "insulin", "cgm0")
 
 
@@ -90,12 +90,12 @@ class BatchedT1DSimEnv:
         self.set_option("adaptive_gut", 1 if adaptive_gut else 0)
         n, dv, ft = self.n, self.device, dtype
         z = lambda *shape, dt=ft: torch.zeros(*shape, dtype=dt, device=dv)
-        # packed state (include/t1d.h): one [44, n] float buffer and one [4, n] int32 buffer; the named
+        # packed state (include/t1d.h): one [45, n] float buffer and one [4, n] int32 buffer; the named
         # tensors are views, so every staged row is one base pointer plus a 32-bit offset on the device
-        self.state = z(44, n)
+        self.state = z(45, n)
         self.x = self.state[0:13]; self.planned = self.state[13]; self.last_qsto = self.state[14]
         self.last_food = self.state[15]; self.last_cgm = self.state[16]; self.prev_risk = self.state[17]
-        self.pts = self.state[18:44]
+        self.pts = self.state[18:44]; self.dbar = self.state[44]
         self.istate = z(4, n, dt=torch.int32)
         self.t = self.istate[0]; self.meta = self.istate[1]; self.next_meal = self.istate[2]; self.episode = self.istate[3]
         self.meta.copy_(torch.from_numpy(pid.astype(np.int32)))            # patient row in bits 0-7
@@ -287,12 +287,14 @@ class BatchedT1DSimEnv:
 
     def info(self):
         """live views of the device outputs and state: read-only for the caller (the reference's info['patient_state']
-        is the solver's own array too, env.py:112).  The clock comes as a COPY: the wrapper shadows it on the host to
-        skip the noise-block refill pre-kernel, so the device array is not the caller's to edit -- a caller who does
-        edit env.t / env.x says so with invalidate_clock() (or goes through load_state_dict)."""
+        is the solver's own array too, env.py:112).  The wrapper shadows the clock on the host to skip the noise-block
+        refill pre-kernel; an in-place torch edit of env.t / env.meta / env.next_meal is noticed (the tensors' version
+        counter) and drops the shadow, so that such an edit cannot leave a stale noise block behind -- for writes the
+        counter cannot see there is invalidate_clock().  (A copy of t per step would cost a 4 MB device copy per launch at
+        1 Mi envs: 6 % of the step.)"""
         return {"sample_time": self.sample_time, "bg": self.bg, "lbgi": self.lbgi, "hbgi": self.hbgi,
                 "risk": self.risk, "meal": self.meal, "insulin": self.insulin, "patient_state": self.x,
-                "t": self.t.clone()}
+                "t": self.t}
 
     def invalidate_clock(self):
         """forget the host's shadow clock: the next steps check every env's own clock for due noise-block refills again.
@@ -435,7 +437,7 @@ class BatchedT1DSimEnv:
         return st.value
 
     # ------------------------------------------------------------------ checkpoint
-    STATE_FORMAT = 3           # = the ABI version whose state words the checkpoint holds (prev_risk, cgm0: since 3)
+    STATE_FORMAT = 4           # = the ABI version whose state words the checkpoint holds (prev_risk, cgm0: since 3; dbar: 4)
 
     def state_dict(self):
         sd = {k: getattr(self, k).clone() for k in _STATE_KEYS + ("cgm", "cgm0")}
@@ -448,7 +450,7 @@ class BatchedT1DSimEnv:
         fmt = sd.get("format")
         if fmt != self.STATE_FORMAT or any(k not in sd for k in _STATE_KEYS + ("cgm", "cgm0")):
             raise _lib.T1DError("checkpoint format %r is not %d (checkpoints written before ABI 3 carry prev_cgm instead of "
-                                "prev_risk and no cgm0): re-create it with this version" % (fmt, self.STATE_FORMAT))
+                                "prev_risk and no cgm0, before ABI 4 no dbar): re-create it with this version" % (fmt, self.STATE_FORMAT))
         for k in _STATE_KEYS + ("cgm", "cgm0"):
             getattr(self, k).copy_(sd[k])
         if self._hist is not None:

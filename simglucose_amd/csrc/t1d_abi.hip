@@ -389,7 +389,7 @@ static int check_batch(const char* who, const t1d_ctx* c, const t1d_batch* b, bo
         return fail(T1D_E_INVALID, std::string(who) + ": n_meals > 0 but meal table pointer is NULL");
     if (b->n_normals < 0) return fail(T1D_E_INVALID, std::string(who) + ": n_normals < 0");
     if (b->n_normals > 0 && !b->normals) return fail(T1D_E_INVALID, std::string(who) + ": n_normals > 0 but normals is NULL");
-    const int known = T1D_BATCH_NO_PUMP | T1D_BATCH_NO_REFILL_DUE | (T1D_AB_FLAGS ? 0xf00 : 0);
+    const int known = T1D_BATCH_NO_PUMP | T1D_BATCH_NO_REFILL_DUE | (T1D_AB_FLAGS ? 0x1f00 : 0);
     if (b->flags & ~known) return fail(T1D_E_INVALID, std::string(who) + ": unknown bit in batch.flags");
     // a ctx is bound to one device: every entry point that takes one launches (and allocates) there
     if (hipSetDevice(c->device) != hipSuccess) return fail(T1D_E_HIP, std::string(who) + ": hipSetDevice failed");
@@ -403,7 +403,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.n = b->n; a.env_offset = b->env_offset; a.seed = b->seed;
     a.x = (T*)b->x; a.planned = (T*)b->planned; a.last_qsto = (T*)b->last_qsto; a.last_food = (T*)b->last_food;
     a.t = b->t; a.meta = b->meta; a.episode = b->episode; a.next_meal = b->next_meal;
-    a.last_cgm = (T*)b->last_cgm; a.ar_e = (T*)b->ar_e; a.pts = (T*)b->pts; a.prev_risk = (T*)b->prev_risk;
+    a.last_cgm = (T*)b->last_cgm; a.ar_e = (T*)b->ar_e; a.pts = (T*)b->pts; a.prev_risk = (T*)b->prev_risk; a.dbar = (T*)b->dbar;
     a.basal = (const T*)b->basal; a.bolus = (const T*)b->bolus; a.cho = (const T*)b->cho;
     a.meal_time = b->meal_time; a.meal_amt = (const T*)b->meal_amt;
     a.normals = b->n_normals > 0 ? (const T*)b->normals : nullptr;
@@ -482,6 +482,7 @@ static bool is_packed(const t1d_batch* b, size_t esz)
     return (const char*)b->planned == xb + 13 * rowb && (const char*)b->last_qsto == xb + 14 * rowb &&
            (const char*)b->last_food == xb + 15 * rowb && (const char*)b->last_cgm == xb + 16 * rowb &&
            (const char*)b->prev_risk == xb + 17 * rowb && (const char*)b->pts == xb + 18 * rowb &&
+           (const char*)b->dbar == xb + (size_t)kRowDbar * rowb &&
            b->next_meal && (const char*)b->meta == (const char*)b->t + (size_t)b->n * 4 &&
            (const char*)b->next_meal == (const char*)b->t + (size_t)b->n * 8 &&
            (size_t)kPackedRows * rowb < ((size_t)1 << 32);

@@ -671,6 +671,11 @@ __device__ __forceinline__ void rk4_substeps(P& p, const MinuteIn<T>& u, T (&x)[
     }
 }
 
+// Dbar = last_Qsto + last_foodtaken * 1000 (t1dpatient.py:130), in ONE form everywhere: the state keeps a copy of it (row
+// `dbar`) that has to equal what eat_minute forms from the two words, bit for bit
+__device__ __forceinline__ double dbar_of(double lq, double lf) { return fma(lf, 1000.0, lq); }
+__device__ __forceinline__ float dbar_of(float lq, float lf) { return fmaf(lf, 1000.0f, lq); }
+
 // Meal ingestion bookkeeping of T1DPatient.step (t1dpatient.py:82-107) + _announce_meal (:222-236).
 // Returns the MinuteIn for the integrator.
 template <int MATH, typename T, typename P>
@@ -693,7 +698,7 @@ __device__ __forceinline__ MinuteIn<T> eat_minute(P& p, const T (&x)[13], T meal
     MinuteIn<T> u;
     u.d_mg = to_eat * T(1000);                              // :121
     u.ins = insulin_upm * p(DP_INSC);                       // :122
-    const T dbar = last_qsto + last_food * T(1000);         // :130
+    const T dbar = dbar_of(last_qsto, last_food);           // :130
     u.has_dbar = dbar > T(0);
     const T dsafe = u.has_dbar ? dbar : T(1);
     if (MATH == 0) {

@@ -45,7 +45,7 @@ template <typename T> struct KArgs {
     int64_t n, env_offset;
     uint64_t seed;
     T* x; T* planned; T* last_qsto; T* last_food; int32_t* t; uint32_t* meta; uint32_t* episode; int32_t* next_meal;
-    T* last_cgm; T* ar_e; T* pts; T* prev_risk;
+    T* last_cgm; T* ar_e; T* pts; T* prev_risk; T* dbar;
     const T* basal; const T* bolus; const T* cho; const int32_t* meal_time; const T* meal_amt;
     const T* normals; const T* x0_override;
     T* cgm; T* bg; T* reward; uint8_t* done; T* lbgi; T* hbgi; T* risk; T* meal; T* insulin; T* cgm0;
@@ -185,9 +185,10 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
     for (int k = 0; k < 13; ++k) at(row(a.x, a.n, k), i) = e.x[k];
     at(a.planned, i) = e.planned; at(a.last_qsto, i) = e.lq; at(a.last_food, i) = e.lf;
     at(a.last_cgm, i) = e.last_cgm; at(a.prev_risk, i) = e.prev_risk;
+    if (a.dbar) at(a.dbar, i) = dbar_of(e.lq, e.lf);
     at(a.t, i) = e.t;
     if (a.next_meal && e.next_meal != e.next_meal_loaded) at(a.next_meal, i) = e.next_meal;
-    at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+    at(a.meta, i) = pid | (e.eating ? T1D_META_EATING : 0u) | (e.planned > T(0) ? T1D_META_PLANNED : 0u) | ((uint32_t)e.cursor << 16);
 }
 
 // Refill of the CGM noise deque (noise_gen.py:30-56): ten new AR(1) -> Johnson-SU points at 15-min
@@ -204,7 +205,8 @@ __device__ __forceinline__ void store_env(const KArgs<T>& a, unsigned i, uint32_
 // rows it reads do not depend on the env's clock (they can be fetched with the rest of the state).
 // pts rows: 0..10 = y (points of the block), 11..21 = M, 22..25 = (y_m, y_{m+1}, M_m, M_{m+1}).
 constexpr int kPtsRows = 26;
-constexpr int kPackedRows = 18 + kPtsRows;            // rows of the packed state buffer (include/t1d.h): 44
+constexpr int kPackedRows = 18 + kPtsRows + 1;        // rows of the packed state buffer (include/t1d.h): 45 (the last one: dbar)
+constexpr int kRowDbar = 18 + kPtsRows;               // 44
 
 #ifndef T1D_REFILL_INLINE
 #define T1D_REFILL_INLINE 1
@@ -546,9 +548,18 @@ __device__ __forceinline__ S1In<T> s1_load(const KArgs<T>& a, unsigned i)
     in.next_meal = at(I(2), i);
     in.basal = at(a.basal, i);
     in.bolus = a.bolus ? (T)at(a.bolus, i) : T(0);
-    in.planned = at(X(13), i); in.lq = at(X(14), i); in.lf = at(X(15), i);
+    const T dbar = at(X(kRowDbar), i);
 #pragma unroll
     for (int k = 0; k < 13; ++k) in.x[k] = at(X(k), i);
+    // The three meal words only where they are live (the env is eating or has a meal planned: ~5 % of the env-minutes);
+    // elsewhere planned = 0 and a minute needs nothing of last_qsto / last_food but Dbar -- (Dbar, 0) stands in for them
+    // (eat_minute forms last_qsto + 1000 last_food: exactly Dbar; a meal that starts overwrites both).  16 bytes less to
+    // read per env-minute.  These loads issue behind the state's: they need the meta word, which was requested first.
+    if ((in.meta & (T1D_META_EATING | T1D_META_PLANNED)) || (T1D_AB_FLAGS && (a.flags & 0x1000))) {
+        in.planned = at(X(13), i); in.lq = at(X(14), i); in.lf = at(X(15), i);
+    } else {
+        in.planned = T(0); in.lq = dbar; in.lf = T(0);
+    }
     return in;
 }
 
@@ -627,15 +638,21 @@ __device__ __forceinline__ void s1_chunk(const KArgs<T>& a, T* ldp, T* lpr, T* l
         on_level(tp.level2);
         if (tp.level2) return;                       // nothing stored: the pass over the list redoes this lane from its loads
     }
-    // bookkeeping is final for this minute: store it now -- the meal words only where they changed (they do
-    // while an env is eating, ~3 % of the minutes: 24 B per env-step of write traffic otherwise)
-    if (e.planned != planned0) at(X(13), i) = e.planned;
-    if (e.lq != lq0) at(X(14), i) = e.lq;
-    if (e.lf != lf0) at(X(15), i) = e.lf;
+    // bookkeeping is final for this minute: store it now -- the meal words (and Dbar beside them) only where they changed:
+    // they do while an env is eating, ~3 % of the minutes.  Where they were not loaded (s1_load) any change means a meal has
+    // just started, which rewrites all three.
+    {
+        const bool live0 = (meta & (T1D_META_EATING | T1D_META_PLANNED)) != 0 || (T1D_AB_FLAGS && (a.flags & 0x1000));
+        const bool changed = live0 ? (e.planned != planned0 || e.lq != lq0 || e.lf != lf0) : (e.eating || e.planned > T(0));
+        if (changed) {
+            at(X(13), i) = e.planned; at(X(14), i) = e.lq; at(X(15), i) = e.lf;
+            at(X(kRowDbar), i) = dbar_of(e.lq, e.lf);
+        }
+    }
     at(I(0), i) = e.t + 1;
     if (e.next_meal != e.next_meal_loaded) at(I(2), i) = e.next_meal;
-    {   // patient id, eating flag, meal cursor: changes when a meal starts, ends or fires
-        const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | ((uint32_t)e.cursor << 16);
+    {   // patient id, eating / planned flags, meal cursor: changes when a meal starts, ends or fires
+        const uint32_t meta1 = pid | (e.eating ? T1D_META_EATING : 0u) | (e.planned > T(0) ? T1D_META_PLANNED : 0u) | ((uint32_t)e.cursor << 16);
         if (meta1 != meta) at(I(1), i) = (int32_t)meta1;
     }
     if (EXTRA) {
@@ -1123,10 +1140,10 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
         const unsigned i = L.i;
 #pragma unroll
         for (int k = 0; k < 13; ++k) at(X(k), i) = L.x[k];
-        if (L.dirty & 1) { at(X(13), i) = L.planned; at(X(14), i) = L.lq; at(X(15), i) = L.lf; }
+        if (L.dirty & 1) { at(X(13), i) = L.planned; at(X(14), i) = L.lq; at(X(15), i) = L.lf; at(X(kRowDbar), i) = dbar_of(L.lq, L.lf); }
         at(I(0), i) = L.t;
         if (L.dirty & 2) at(I(2), i) = L.next_meal;
-        if (L.dirty & 4) at(I(1), i) = (int32_t)(L.pid | (L.eating ? T1D_META_EATING : 0u) | ((uint32_t)L.cursor << 16));
+        if (L.dirty & 5) at(I(1), i) = (int32_t)(L.pid | (L.eating ? T1D_META_EATING : 0u) | (L.planned > T(0) ? T1D_META_PLANNED : 0u) | ((uint32_t)L.cursor << 16));
         if (st != 1) at(X(16), i) = L.last_cgm;
         const T rp = at(X(17), i);                          // risk index of the previous step's CGM
         const T cgm_out = L.cgm_sum, bg_out = L.bg_sum;

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert hasattr(L, n), n
-    assert L.t1d_abi_version() == 3
+    assert L.t1d_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_ctx_create_rejects_bad_arguments_without_touching_a_gpu():

@@ -660,13 +660,48 @@ def test_clock_edited_behind_the_wrapper_still_refills_noise_blocks():
     envs[0].t += 45                                   # behind the wrapper's back: sample #150 (a new block) is now 4 steps away
     sd = envs[1].state_dict(); sd["t"] = sd["t"] + 45
     envs[1].load_state_dict(sd)
-    assert isinstance(envs[0].info()["t"], torch.Tensor) and envs[0].info()["t"].data_ptr() != envs[0].t.data_ptr()
     pts_before = envs[0].pts[:11].clone()
     for _ in range(12):
         envs[0].step(b); envs[1].step(b)
     assert envs[0]._clock is None
     assert not torch.equal(pts_before, envs[0].pts[:11])              # the block was rebuilt
     assert torch.equal(envs[0].pts, envs[1].pts) and torch.equal(envs[0].cgm, envs[1].cgm) and torch.equal(envs[0].t, envs[1].t)
+    assert envs[0].sync() == 0 and envs[1].sync() == 0
+
+
+@pytest.mark.parametrize("sensor", ["Navigator", "Dexcom"])
+def test_dbar_row_and_planned_bit_invariants(sensor):
+    """ABI 4: the state keeps Dbar = last_qsto + 1000 last_food beside the two words, and bit 9 of meta says
+    planned_meal > 0.  Both hold after every step, through meals (table): that is what lets the one-minute kernels skip
+    the three meal words of envs that neither eat nor have a meal planned (they read Dbar instead).  The run with the
+    wrapper's shadow clock dropped before every step (the refill pre-kernel checks every env's clock) is bit-identical."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    n = 64 * 9 - 3
+    pid = np.arange(n) % 30
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=6 * 60 + 30, seed=17, device="cuda:0")
+    envs = []
+    for _ in range(2):
+        e = _mk(patient=pid, sensor=sensor, noise="philox", seed=6, n_sub=4)
+        e.set_meals(mt, ma)
+        e.reset()
+        envs.append(e)
+    b = torch.as_tensor(_basal(pid), device="cuda:0")
+    st = int(envs[0].sample_time)
+    seen_live = False
+    for k in range(240 // st):
+        a = b * (0.5 + 0.25 * (k % 5))
+        envs[0].step(a)
+        envs[1].invalidate_clock()
+        envs[1].step(a)
+        if k % 7 == 0 or k == 240 // st - 1:
+            for e in envs:
+                assert float((e.dbar - (e.last_qsto + 1000.0 * e.last_food)).abs().max()) <= 1e-12 * float(e.dbar.abs().max() + 1)
+                assert torch.equal((e.meta & 0x200) != 0, e.planned > 0)
+            seen_live = seen_live or bool((envs[0].meta & 0x300).ne(0).any())
+            for key in ("x", "cgm", "bg", "reward", "planned", "last_qsto", "last_food", "dbar", "meta", "next_meal", "pts", "t"):
+                assert torch.equal(getattr(envs[0], key), getattr(envs[1], key)), (k, key)
+    assert seen_live and int(envs[0].t[5]) == 240
     assert envs[0].sync() == 0 and envs[1].sync() == 0
 
 
@@ -754,35 +789,48 @@ def test_full_size_24h_run_sampled_envs_match_oracle(adaptive):
     pool_s = [p[torch.as_tensor(sample, device=e.device)].cpu().numpy() for p in pool]
     orc = O.OracleEnv(pid[sample], sensor="Navigator", normals=z, integrator="split_adaptive" if adaptive else "split", n_sub=4)
     ref = O.OracleEnv(pid[sample], sensor="Navigator", normals=z, integrator="dopri")      # SciPy's DOPRI5 as the reference drives it
+    tight = O.OracleEnv(pid[sample], sensor="Navigator", normals=z, integrator="rk4", n_sub=48) if adaptive else None   # the ODE's own solution
     sidx = torch.as_tensor(sample, device=e.device)
     o0, r0 = e.reset(), orc.reset()
     ref.reset()
+    if tight is not None:
+        tight.reset()
     assert np.abs(o0[sidx].cpu().numpy() - r0["cgm"]).max() < 1e-9
     worst, worst_scipy = 0.0, 0.0
     alive = np.ones(len(sample), bool)                       # fixed steps: compared while BG stays out of the clamp regime
-    worst_env = np.zeros(len(sample))
+    worst_env = np.zeros(len(sample)); worst_tight = np.zeros(len(sample)); scipy_tight = np.zeros(len(sample))
     for k in range(K):
         e.step(pool[k % 8])
         r = orc.step(pool_s[k % 8], None, cho[k:k + 1])
         rr = ref.step(pool_s[k % 8], None, cho[k:k + 1])
+        rt = tight.step(pool_s[k % 8], None, cho[k:k + 1]) if tight is not None else None
         if not adaptive:
             alive &= rr["bg"] >= 20.0                        # level 1 everywhere is not held to the bar at the x3 >= 0 clamp; the default is
+        if rt is not None:
+            scipy_tight = np.maximum(scipy_tight, np.abs(rr["bg"] - rt["bg"]))
         if k % 16 == 15 or k == K - 1:
             bg = e.bg[sidx].cpu().numpy()
             worst = max(worst, np.abs(bg - r["bg"]).max(), np.abs(e.cgm[sidx].cpu().numpy() - r["cgm"]).max())
             if alive.any():
                 worst_scipy = max(worst_scipy, np.abs(bg - rr["bg"])[alive].max())
                 worst_env = np.maximum(worst_env, np.where(alive, np.abs(bg - rr["bg"]), 0.0))
+            if rt is not None:
+                worst_tight = np.maximum(worst_tight, np.abs(bg - rt["bg"]))
     assert worst < 1e-8, worst
-    # Against SciPy's adaptive solution the fixed-step schemes hold 1e-3 on the reference's own scenarios (fixtures
-    # G2/G5/G6/G10, upstream CSV); on random six-meal days with meals up to ~110 g about one env-day in twelve goes
-    # beyond it (worst ~6e-3, steep gastric-emptying patients after large meals; SciPy's default tolerance is itself
-    # up to 2.6e-3 from a tight solve there) -- DESIGN.md section 4.  n_sub = 8 is the setting for those.
-    # With the adaptive gut refinement (half-size gut steps in the < 1 % of env-minutes that cross a transition fast)
-    # what is left is SciPy's own distance from the tight solve.
+    # Measured on this workload (bench.py, 1 024 envs x 24 h): against a tight solve of the ODE the default scheme is within
+    # 1.04e-3 (99.8 % of the env-days within 1e-3, median 2.6e-5); SciPy's own default tolerance is up to 3.7e-3 from that
+    # solve (99.2 % within 1e-3), so against SciPy 99.1 % of the env-days are within 1e-3 and the worst one is SciPy's own
+    # worst.  The bounds below are those figures plus a margin: a scheme twice as far off fails them.
+    # Level 1 in every minute (adaptive_gut = 0): about one env-day in twelve goes beyond 1e-3 (worst ~6e-3, steep
+    # gastric-emptying patients after large meals) -- DESIGN.md section 4.
     if adaptive:
-        assert alive.sum() > 250 and worst_scipy < 4e-3, (alive.sum(), worst_scipy)
-        assert (worst_env <= 1e-3).mean() > 0.97 and np.median(worst_env) < 1.5e-4, ((worst_env <= 1e-3).mean(), np.median(worst_env))
+        assert worst_tight.max() < 1.5e-3 and (worst_tight <= 1e-3).mean() >= 0.99 and np.median(worst_tight) < 6e-5, \
+            (worst_tight.max(), (worst_tight <= 1e-3).mean(), np.median(worst_tight))
+        assert (worst_env <= 1e-3).mean() >= 0.985 and np.median(worst_env) < 1.0e-4, ((worst_env <= 1e-3).mean(), np.median(worst_env))
+        # where the kernel is further than 1e-3 from SciPy, SciPy is at least as far from the ODE's solution
+        far = worst_env > 1e-3
+        assert (scipy_tight[far] > 0.7e-3).all(), (worst_env[far], scipy_tight[far])
+        assert worst_scipy < 1.2 * max(scipy_tight.max(), 1e-3) + 1e-3, (worst_scipy, scipy_tight.max())
     else:
         assert alive.sum() > 250 and worst_scipy < 1e-2, (alive.sum(), worst_scipy)
         assert (worst_env <= 1e-3).mean() > 0.85 and np.median(worst_env) < 4e-4, ((worst_env <= 1e-3).mean(), np.median(worst_env))

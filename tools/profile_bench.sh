@@ -6,7 +6,7 @@
 # usage: tools/profile_bench.sh TAG [bench args]
 set -e
 tag=${1:-v1}; shift || true
-round=${T1D_ROUND:-r02}
+round=${T1D_ROUND:-r03}
 root=$PWD
 out=$root/gpurun_out
 mkdir -p $out
