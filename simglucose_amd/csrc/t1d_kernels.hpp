@@ -1095,18 +1095,20 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
         else { tp.f1 = kgut_flux(pl, u, L.x[0], L.x[1]); tp.level2 = false; }
         return u;
     };
-    // one minute at a compile-time level: parameters gathered into registers for the sub-step loops, step sizes from LDS
-    auto integrate = [&](auto level, SnLane<T>& L, const MinuteIn<T>& u, T f1) {
-        constexpr int LEVEL = decltype(level)::value;
-        ParsLdsS<T, STRIDE> pl{ldp, (int)L.pid};
-        PropLdsS<T, STRIDE> pr{lpr, (int)L.pid};
-        ParsReg<T> p;
+    // the parameters of a chunk's minute loop, gathered into registers once per chunk: 16 model constants + the 4 gut weights
+    // of level 1
+    auto gather_pars = [&](ParsReg<T>& p, uint32_t pid) {
+        ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(kSplitPars) / sizeof(int)); ++k) p.v[kSplitPars[k]] = pl(kSplitPars[k]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p.v[kSplitW(LEVEL) + k] = pl(kSplitW(LEVEL) + k);
+        for (int k = 0; k < 4; ++k) p.v[kSplitW(1) + k] = pl(kSplitW(1) + k);
+    };
+    // one minute of a chunk at level 1: step sizes from LDS
+    auto integrate = [&](ParsReg<T>& p, SnLane<T>& L, const MinuteIn<T>& u, T f1) {
+        PropLdsS<T, STRIDE> pr{lpr, (int)L.pid};
         p.pin_split();
-        split_level<LEVEL, T, ParsReg<T>, decltype(pr), true, true>(p, pr, u, L.x, a.n_sub, f1, false, lconst + (LEVEL == 1 ? 8 : 13));
+        split_level<1, T, ParsReg<T>, decltype(pr), true, true>(p, pr, u, L.x, a.n_sub, f1, false, lconst + 8);
     };
     // clock, Gsub (t1dpatient.py:217-218), the CGM sample if one is due (cgm.py:26-36), the step's means (env.py:78-81)
     auto minute_tail = [&](SnLane<T>& L, T meal) {
@@ -1289,6 +1291,8 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
         if ((int64_t)i0 < a.n) {
             load_lane(L, i0);
             left = false;
+            ParsReg<T> p;
+            gather_pars(p, L.pid);
             while (L.m < a.minutes) {
                 T meal = T(0);
                 TierPre<T> tp{T(0), false};
@@ -1317,7 +1321,7 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
 #if T1D_S1_PHASE_PRIO
                 __builtin_amdgcn_s_setprio(0);              // the integration fills the issue slots the other phases leave
 #endif
-                integrate(std::integral_constant<int, 1>(), L, u, tp.f1);
+                integrate(p, L, u, tp.f1);
 #if T1D_S1_PHASE_PRIO
                 __builtin_amdgcn_s_setprio(T1D_S1_PHASE_PRIO);
 #endif
