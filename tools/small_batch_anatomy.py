@@ -1,6 +1,10 @@
+#!/usr/bin/env python3
+"""Tuning aid (needs a -DT1D_AB_FLAGS=1 build in T1D_LIB_PATH): the one-minute launch at 1 024 and 131 072 envs as shipped, with
+level 1 in every minute, without the integration (flag 0x800), without integration and risk index (0x900) and in place:
+what the group of level-2 lanes that ends a small launch costs (profiles/r03/small_batches.log).  GPU box."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simglucose_amd.batch_env import BatchedT1DSimEnv
 from simglucose_amd import params, scenario_batch
 dt = torch.float64
