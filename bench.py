@@ -222,6 +222,43 @@ def accuracy_block(env, pool, mt, ma, integ, n_sub, sensor, minutes, n_sample, s
     return out, rk4
 
 
+def weak_probe(a, dev, dt, tab, rank, world, steps=300, warmup=300):
+    """The workload with a.envs envs on EVERY rank (rank r = envs [r a.envs, (r + 1) a.envs) of the job): barrier, `steps`
+    launches, barrier, MAX over ranks -- the figure `--scaling weak` reports, taken beside a strong-scaling run."""
+    import torch
+    import torch.distributed as dist
+    from simglucose_amd.batch_env import BatchedT1DSimEnv
+    from simglucose_amd import params, scenario_batch
+    n, off = a.envs, rank * a.envs
+    pid = (off + np.arange(n, dtype=np.int64)) % 30
+    env = BatchedT1DSimEnv(patient=pid, sensor=a.sensor, dtype=dt, device=dev, n_sub=a.n_sub, seed=1234, env_offset=off,
+                           noise="philox", extra_outputs=False)
+    env.set_option("integrator", {"auto": -1, "rk4": 0, "split": 1}[a.integrator])
+    env.set_option("adaptive_gut", 0 if a.fixed_step else (2 if a.in_place else 1))
+    st = env.minutes_per_step
+    g = torch.Generator(device=dev); g.manual_seed(99 + rank)
+    start = torch.zeros(n, dtype=torch.int32, device=dev) if a.midnight_start else torch.randint(0, 1440, (n,), generator=g, device=dev, dtype=torch.int32)
+    mt, ma = scenario_batch.random_meal_tables(n, days=1 + (steps + warmup) * st // 1440, start_minute_of_day=start, seed=1000, device=dev, dtype=dt, env_offset=off)
+    env.set_meals(mt, ma)
+    basal0 = torch.as_tensor(tab[pid, params.P_COL["u2ss"]] * tab[pid, params.P_COL["BW"]] / 6000.0, dtype=dt, device=dev)
+    pool = [(basal0 * 2.0 * torch.rand(n, generator=g, device=dev, dtype=torch.float64).to(dt)).contiguous() for _ in range(4)]
+    env.reset()
+    for k in range(warmup):
+        env.step(pool[k % 4])
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(pool[k % 4])
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    status = env.sync(raise_on_status=False)
+    wall = float(tw.item())
+    return {"scaling": "weak", "value": n * world * steps * st / wall, "unit": "env-steps/s", "envs_per_gpu": n, "envs_total": n * world,
+            "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3, "status_bits": status,
+            "note": "the same workload with %d envs on every rank, timed after the headline region (barrier + MAX over ranks as there)" % n}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +288,7 @@ def main(argv=None):
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--accuracy-envs", type=int, default=1024)
     ap.add_argument("--accuracy-minutes", type=int, default=1440, help="north_star: a 24 h scenario")
+    ap.add_argument("--no-weak-probe", action="store_true", help="N > 1, strong scaling: skip the full-batch-per-rank measurement after the timed region")
     ap.add_argument("--rk4-steps", type=int, default=200, help="timed launches of the north_star_rk4 leg (classical RK4, same workload)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE/WRITE_SIZE), copied into roofline.traffic")
@@ -293,7 +331,8 @@ def main(argv=None):
     dev = torch.device("cuda", local)
     # T1D_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL init, barriers, max-reduce) with a single rank too:
     # a one-GPU box can rehearse what the N > 1 launches do
-    use_dist = world > 1 or (os.environ.get("T1D_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    # (=2: and the weak-scaling probe that otherwise only runs with N > 1)
+    use_dist = world > 1 or (os.environ.get("T1D_BENCH_FORCE_DIST") in ("1", "2") and "MASTER_ADDR" in os.environ)
     if use_dist:
         # RCCL prints its version banner on stdout while the communicator comes up: send that to stderr, so that
         # stdout carries nothing but the one JSON line
@@ -381,6 +420,14 @@ def main(argv=None):
         wall = float(tw.item())
     kern_ms = ev0.elapsed_time(ev1) / a.steps
     total_env_steps = n_global * a.steps * st
+    # N > 1 under strong scaling: each rank's shard is small and its launch latency-bound; the same job
+    # with a full-size batch on every rank (what --scaling weak times) is measured beside it, outside the timed region
+    weak = None
+    if use_dist and (world > 1 or os.environ.get("T1D_BENCH_FORCE_DIST") == "2") and a.scaling == "strong" and not a.no_weak_probe:
+        try:
+            weak = weak_probe(a, dev, dt, tab, rank, world)
+        except Exception as e:                      # (collective inside: every rank fails or none; the headline line survives)
+            weak = {"error": repr(e)}
     bg = env.bg
     sane = bool(torch.isfinite(bg).all()) and status == 0
 
@@ -390,6 +437,8 @@ def main(argv=None):
             kernel_name = {"split": "void t1d::step1_kernel<%s, 32, false, false>(t1d::KArgs<%s>, int)",
                            "split_adaptive": "void t1d::step1_kernel<%s, 32, false, true>(t1d::KArgs<%s>, int)" if a.in_place
                                              else "void t1d::step1d_kernel<%s, false>(t1d::KArgs<%s>, int)"}[integ] % (tname, tname)
+        elif integ != "rk4" and a.dtype == "f64" and n >= 393216 and not a.in_place:       # (the library's default threshold: t1d.h "multi_minute_kernel")
+            kernel_name = "void t1d::stepn_kernel<double, false, false>(t1d::KArgs<double>, t1d::PidArgs<double>, int, int, int)"
         else:
             kernel_name = "void t1d::step_kernel<%d, %s, false>(t1d::KArgs<%s>)" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname, tname)
         # last recorded PMC measurements of this exact configuration (tools/profile_bench.sh): HBM bytes, VALU instructions
@@ -426,7 +475,7 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype], "valu": valu},
-            "accuracy": accuracy, "north_star_rk4": rk4,
+            "accuracy": accuracy, "north_star_rk4": rk4, "weak_scaling_probe": weak,
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
         }
