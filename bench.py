@@ -437,8 +437,8 @@ def main(argv=None):
             kernel_name = {"split": "void t1d::step1_kernel<%s, 32, false, false>(t1d::KArgs<%s>, int)",
                            "split_adaptive": "void t1d::step1_kernel<%s, 32, false, true>(t1d::KArgs<%s>, int)" if a.in_place
                                              else "void t1d::step1d_kernel<%s, false>(t1d::KArgs<%s>, int)"}[integ] % (tname, tname)
-        elif integ != "rk4" and a.dtype == "f64" and n >= 393216 and not a.in_place:       # (the library's default threshold: t1d.h "multi_minute_kernel")
-            kernel_name = "void t1d::stepn_kernel<double, false, false>(t1d::KArgs<double>, t1d::PidArgs<double>, int, int, int)"
+        elif integ != "rk4" and n >= (262144 if a.dtype == "f64" else 393216) and not a.in_place:       # (the library's default thresholds: t1d.h "multi_minute_kernel")
+            kernel_name = "void t1d::stepn_kernel<%s, false, false>(t1d::KArgs<%s>, t1d::PidArgs<%s>, int, int, int)" % (tname, tname, tname)
         else:
             kernel_name = "void t1d::step_kernel<%d, %s, false>(t1d::KArgs<%s>)" % ({"rk4": 3, "split": 4, "split_adaptive": 7}[integ], tname, tname)
         # last recorded PMC measurements of this exact configuration (tools/profile_bench.sh): HBM bytes, VALU instructions

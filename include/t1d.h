@@ -244,15 +244,16 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  *   steps, env.py:75-81) on the packed layout in one launch of the persistent multi-minute kernel -- the state stays in
  *   registers across the minutes; a lane that the step-size rule puts at level 2 leaves a record in LDS (its state at the
  *   start of that minute) and the rest of its wave carries on at level 1; waves without a chunk to work on finish the
- *   records, every lane at its own level, beside the last chunks.  1 (default) = fp64 batches of "multi_minute_min_envs"
- *   (393 216) envs or more, where it beats the generic kernel (Dexcom steps, fp64: 147 against 184 us at 512 Ki envs, 257
- *   against 339 at 1 Mi, 883 against 1254 at 4 Mi; level at 256 Ki; fp32 within 6 % of the generic kernel at every size);
+ *   records, every lane at its own level, beside the last chunks.  1 (default) = batches of "multi_minute_min_envs"
+ *   (fp64: 262 144) / "multi_minute_min_envs_f32" (393 216) envs or more, where it beats the generic kernel (Dexcom steps,
+ *   us per step, generic / persistent: fp64 95 / 92 at 256 Ki envs, 133 / 101 at 384 Ki, 174 / 120 at 512 Ki, 324 / 213
+ *   at 1 Mi; fp32 68 / 60 at 384 Ki, 143 / 110 at 1 Mi; below the thresholds the generic kernel wins: tools/mm_thresholds.py);
  *   0 = never (the generic kernel: a wave runs at the level of its most refined lane); 2 = always.
  *   "park_cap": records per workgroup (0 = what fits in LDS beside the tables; a flagged lane that finds none free is
  *   taken again from its loads at the end of the launch, in place).
  * "rollout_launches": t1d_rollout_pid / t1d_rollout_bb as one launch of that kernel per step, the controller fused into
- *   it: 1 (default) = fp64 batches of "rollout_launches_min_envs" (393 216) envs or more; 0 = never (all steps inside one
- *   launch of the generic roll-out kernel); 2 = always. */
+ *   it: 1 (default) = batches of "rollout_launches_min_envs" (fp64: 524 288) / "rollout_launches_min_envs_f32" (786 432)
+ *   envs or more; 0 = never (all steps inside one launch of the generic roll-out kernel); 2 = always. */
 int t1d_ctx_set_option(t1d_ctx* ctx, const char* name, int64_t value);
 
 /* Host-only helper (no device needed): the tables of the split integrator for one patient row

@@ -41,10 +41,10 @@ struct t1d_ctx {
     long long* d_trace = nullptr;    // T1D_S1_TRACE builds
     int defer_min_chunks = 1;        // adaptive_gut = 1: one-minute launches set lanes of level 2 aside from this many chunks per CU up
     int multi_minute_kernel = 1;     // steps of several minutes (minutes <= sample_time) on the packed layout through the persistent kernel with the state in registers across the minutes: 0 never (generic kernel), 1 = fp64 batches of multi_minute_min_envs envs or more, 2 always
-    int multi_minute_min_envs = 393216;
+    int multi_minute_min_envs = 262144, multi_minute_min_envs_f32 = 393216;      // measured crossovers: tools/mm_thresholds.py
     int park_cap = 0;                // records for set-aside lanes per workgroup of that kernel (0 = what fits in LDS; tests force the overflow path with a small one)
     int rollout_launches = 1;        // closed-loop roll-outs as one launch of that kernel per step: 0 never (all steps inside one launch of the generic kernel), 1 from rollout_launches_min_envs envs up, 2 always
-    int rollout_launches_min_envs = 393216;
+    int rollout_launches_min_envs = 524288, rollout_launches_min_envs_f32 = 786432;
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
     std::vector<double> dpar;    // host copy of the derived-parameter table
 };
@@ -342,9 +342,11 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         {"defer_min_chunks", &t1d_ctx::defer_min_chunks, 0, 65535},
         {"multi_minute_kernel", &t1d_ctx::multi_minute_kernel, 0, 2},
         {"multi_minute_min_envs", &t1d_ctx::multi_minute_min_envs, 0, 1 << 28},
+        {"multi_minute_min_envs_f32", &t1d_ctx::multi_minute_min_envs_f32, 0, 1 << 28},
         {"park_cap", &t1d_ctx::park_cap, 0, 65535},
         {"rollout_launches", &t1d_ctx::rollout_launches, 0, 2},
         {"rollout_launches_min_envs", &t1d_ctx::rollout_launches_min_envs, 0, 1 << 28},
+        {"rollout_launches_min_envs_f32", &t1d_ctx::rollout_launches_min_envs_f32, 0, 1 << 28},
         {"s1_blocks", &t1d_ctx::s1_blocks, 0, 65535},
         {"adaptive_gut", &t1d_ctx::adaptive_gut, 0, 3},
         {"single_minute_kernel", &t1d_ctx::single_minute_kernel, 0, 1},
@@ -577,7 +579,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
     size_t dyn_n = 0;
     // (measured, Dexcom steps: fp64 147 against 184 us at 512 Ki envs, 257 against 339 at 1 Mi, 883 against 1254 at 4 Mi, level
     // at 256 Ki, the generic kernel ahead below; fp32 within 6 % of the generic kernel at every size)
-    const bool want_n = c->multi_minute_kernel == 2 || (c->multi_minute_kernel == 1 && b->dtype == T1D_F64 && b->n >= c->multi_minute_min_envs);
+    const bool want_n = c->multi_minute_kernel == 2 || (c->multi_minute_kernel == 1 && b->n >= (b->dtype == T1D_F64 ? c->multi_minute_min_envs : c->multi_minute_min_envs_f32));
     const int cap = p.ok && minutes > 1 && want_n ? stepn_park_cap(c, p, esz, minutes, &dyn_n) : -1;
     const bool persistent = p.ok && (minutes == 1 || cap >= 0);
     size_t dyn = 0;
@@ -700,7 +702,7 @@ static int launch_rollout(const char* who, t1d_ctx* c, const t1d_batch* b, int n
     // Large batches: one launch of the persistent multi-minute kernel per step, the controller in its prologue -- the
     // step-size rule's lanes of level 2 are set aside, where the all-steps-in-one-launch kernel runs each wave at the level
     // of its most refined lane.  The noise-block refill goes ahead of every step as in t1d_step (the clocks are the envs').
-    const bool per_step = c->rollout_launches == 2 || (c->rollout_launches == 1 && b->dtype == T1D_F64 && b->n >= c->rollout_launches_min_envs);
+    const bool per_step = c->rollout_launches == 2 || (c->rollout_launches == 1 && b->n >= (b->dtype == T1D_F64 ? c->rollout_launches_min_envs : c->rollout_launches_min_envs_f32));
     const bool split_refill = variant != 0 && c->split_refill && minutes <= (int)c->sensor[5];
     if (per_step && c->multi_minute_kernel) {       // (a step of one minute too: the kernel takes any minutes >= 1)
         const PersistPlan p = plan_persistent(c, b, n_sub, split, split_refill);

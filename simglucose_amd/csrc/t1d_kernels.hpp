@@ -1249,17 +1249,20 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
             // ---- records: each lane from the minute it was parked in (which the rule, on the same state, puts at level 2
             // again); a word of the redo map: the envs of a chunk that found no record free, from their loads.  Every lane
             // at its own level, in place.
+            // (Every lane reads -- the idle ones a record or env of a neighbour, and do nothing with it: a load under a
+            // divergent branch writes only the active lanes of its registers, which makes the compiler keep the previous
+            // item's values alive in the others across the whole item loop: 27 register pairs spilled and reloaded per item.)
             SnLane<T> L;
             bool active;
             if (w_n > 0) {
                 sn_wait_records(park_i, park_cap, w_lo, w_n, lane, a.status);
                 active = (int)lane < w_n;
-                if (active) { sn_unpark(L, park_t, park_i, park_cap, w_lo + (int)lane); }
+                sn_unpark(L, park_t, park_i, park_cap, w_lo + (active ? (int)lane : 0));
             } else {
                 const unsigned i = (unsigned)(first + w_redo) * 64u + lane;
                 __builtin_assume(i < (1u << 28));
                 active = ((redo[w_redo] >> lane) & 1ull) != 0ull;
-                if (active) load_lane(L, i);
+                load_lane(L, (int64_t)i < a.n ? i : (unsigned)(a.n - 1));
             }
             for (;;) {
                 const bool on = active && L.m < a.minutes;
@@ -1286,14 +1289,13 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
         // ---- a chunk
         const unsigned i0 = (unsigned)(first + w_chunk) * 64u + lane;
         __builtin_assume(i0 < (1u << 28));
-        bool left = true;                                   // lanes beyond the batch have nothing to finish
+        bool left = (int64_t)i0 >= a.n;                     // lanes beyond the batch have nothing to finish
         SnLane<T> L;
-        if ((int64_t)i0 < a.n) {
-            load_lane(L, i0);
-            left = false;
+        {
+            load_lane(L, left ? (unsigned)(a.n - 1) : i0);  // (every lane loads: see above)
             ParsReg<T> p;
             gather_pars(p, L.pid);
-            while (L.m < a.minutes) {
+            while (!left && L.m < a.minutes) {
                 T meal = T(0);
                 TierPre<T> tp{T(0), false};
                 // the lane as it stands at the start of the minute: what a record holds
