@@ -451,7 +451,9 @@ def main(argv=None):
                 valu_insts = tj.get("valu_insts_per_launch")
         except (OSError, KeyError, ValueError):
             pass
-        algo = ALGO_BYTES[a.dtype] * n * st               # algorithmic bytes per launch (per GPU)
+        # algorithmic bytes per launch (per GPU): the state is read and written once per launch by the persistent multi-minute
+        # kernel, once per minute otherwise
+        algo = ALGO_BYTES[a.dtype] * n * (1 if "stepn_kernel" in kernel_name else st)
         ach = algo / (kern_ms * 1e-3) / 1e9
         valu = None
         if valu_insts:
