@@ -250,7 +250,9 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  *   at 1 Mi; fp32 68 / 60 at 384 Ki, 143 / 110 at 1 Mi; below the thresholds the generic kernel wins: tools/mm_thresholds.py);
  *   0 = never (the generic kernel: a wave runs at the level of its most refined lane); 2 = always.
  *   "park_cap": records per workgroup (0 = what fits in LDS beside the tables; a flagged lane that finds none free is
- *   taken again from its loads at the end of the launch, in place).
+ *   taken again from its loads at the end of the launch, in place).  "record_group_min" (1..64, default 64): that many
+ *   waiting records go ahead of a wave's next chunk (fewer: the records start earlier but in emptier waves -- measured
+ *   slower from 512 Ki envs up, 3-5 % faster at 256 Ki).
  * "rollout_launches": t1d_rollout_pid / t1d_rollout_bb as one launch of that kernel per step, the controller fused into
  *   it: 1 (default) = batches of "rollout_launches_min_envs" (fp64: 524 288) / "rollout_launches_min_envs_f32" (786 432)
  *   envs or more; 0 = never (all steps inside one launch of the generic roll-out kernel); 2 = always. */

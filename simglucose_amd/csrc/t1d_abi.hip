@@ -43,6 +43,7 @@ struct t1d_ctx {
     int multi_minute_kernel = 1;     // steps of several minutes (minutes <= sample_time) on the packed layout through the persistent kernel with the state in registers across the minutes: 0 never (generic kernel), 1 = fp64 batches of multi_minute_min_envs envs or more, 2 always
     int multi_minute_min_envs = 262144, multi_minute_min_envs_f32 = 393216;      // measured crossovers: tools/mm_thresholds.py
     int park_cap = 0;                // records for set-aside lanes per workgroup of that kernel (0 = what fits in LDS; tests force the overflow path with a small one)
+    int record_group_min = 64;       // the multi-minute kernel: that many waiting records go ahead of a wave's next chunk
     int rollout_launches = 1;        // closed-loop roll-outs as one launch of that kernel per step: 0 never (all steps inside one launch of the generic kernel), 1 from rollout_launches_min_envs envs up, 2 always
     int rollout_launches_min_envs = 524288, rollout_launches_min_envs_f32 = 786432;
     std::vector<double> ptab;    // the caller's table, kept for rebuilding the split tables
@@ -344,6 +345,7 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         {"multi_minute_min_envs", &t1d_ctx::multi_minute_min_envs, 0, 1 << 28},
         {"multi_minute_min_envs_f32", &t1d_ctx::multi_minute_min_envs_f32, 0, 1 << 28},
         {"park_cap", &t1d_ctx::park_cap, 0, 65535},
+        {"record_group_min", &t1d_ctx::record_group_min, 1, 64},
         {"rollout_launches", &t1d_ctx::rollout_launches, 0, 2},
         {"rollout_launches_min_envs", &t1d_ctx::rollout_launches_min_envs, 0, 1 << 28},
         {"rollout_launches_min_envs_f32", &t1d_ctx::rollout_launches_min_envs_f32, 0, 1 << 28},
@@ -536,7 +538,7 @@ template <typename T, bool EXTRA, bool CTRL>
 static int launch_stepn(t1d_ctx* c, const t1d_batch* b, const PersistPlan& p, int cap, size_t dyn, int minutes, int n_sub, const PidArgs<T>& pa, hipStream_t s)
 {
     T1D_HIP(allow_lds(c, (const void*)stepn_kernel<T, EXTRA, CTRL>, dyn));
-    const int mode = (c->adaptive_gut != 0 ? 1 : 0) | (c->adaptive_gut == 2 ? 2 : 0);
+    const int mode = (c->adaptive_gut != 0 ? 1 : 0) | (c->adaptive_gut == 2 ? 2 : 0) | (c->record_group_min << 8);
     hipLaunchKernelGGL((stepn_kernel<T, EXTRA, CTRL>), dim3(p.blocks), dim3(sn_threads<T>()), dyn, s, make_args<T>(c, b, minutes, n_sub), pa,
                        p.nchunks, cap, mode);
     return T1D_OK;

@@ -986,7 +986,8 @@ __device__ __forceinline__ void sn_unpark(SnLane<T>& L, const T* pt, const int* 
 #define T1D_SN_WAVES_F32 4
 #endif
 template <typename T> constexpr int sn_threads() { return 256 * (sizeof(T) == 4 ? T1D_SN_WAVES_F32 : T1D_SN_WAVES); }
-// mode bit 1: step sizes by the rule (else level 1 in every minute); bit 2: every env through the redo pass (in place)
+// mode bit 1: step sizes by the rule (else level 1 in every minute); bit 2: every env through the redo pass (in place);
+// bits 8..: that many waiting records go ahead of a wave's next chunk
 template <typename T, bool EXTRA, bool CTRL>
 __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T> a, const PidArgs<T> c, int nchunks, int park_cap, int mode)
 {
@@ -1004,6 +1005,7 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
     const int first = (int)blockIdx.x * per_block;
     const int count = nchunks - first < per_block ? nchunks - first : per_block;
     const bool tiered = (mode & 1) != 0, all_redo = (mode & 2) != 0;
+    const int group_min = mode >> 8;                        // records that go ahead of the next chunk (1..64)
     if (threadIdx.x == 0) {
         queue = 0; taken = 0; parked = 0; passed = all_redo ? count : 0; redo_any = 0; redo_next = 0;
         T hc[5];
@@ -1201,8 +1203,9 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
                 int pk = __hip_atomic_load(&parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 pk = pk < park_cap ? pk : park_cap;
                 int tk = __hip_atomic_load(&taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (pk - tk >= 64 && __hip_atomic_compare_exchange_strong(&taken, &tk, tk + 64, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    w_lo = tk; w_n = 64; full = true;
+                const int av = pk - tk < 64 ? pk - tk : 64;
+                if (av >= group_min && __hip_atomic_compare_exchange_strong(&taken, &tk, tk + av, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    w_lo = tk; w_n = av; full = true;
                 }
             }
             const int cc = (all_redo || full) ? count : atomicAdd(&queue, 1);
