@@ -246,8 +246,8 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  *   start of that minute) and the rest of its wave carries on at level 1; waves without a chunk to work on finish the
  *   records, every lane at its own level, beside the last chunks.  1 (default) = batches of "multi_minute_min_envs"
  *   (fp64: 262 144) / "multi_minute_min_envs_f32" (393 216) envs or more, where it beats the generic kernel (Dexcom steps,
- *   us per step, generic / persistent: fp64 95 / 92 at 256 Ki envs, 133 / 101 at 384 Ki, 174 / 120 at 512 Ki, 324 / 213
- *   at 1 Mi; fp32 68 / 60 at 384 Ki, 143 / 110 at 1 Mi; below the thresholds the generic kernel wins: tools/mm_thresholds.py);
+ *   us per step, generic / persistent: fp64 96 / 84 at 256 Ki envs, 134 / 93 at 384 Ki, 172 / 117 at 512 Ki, 324 / 209
+ *   at 1 Mi; fp32 65 / 59 at 384 Ki, 141 / 117 at 1 Mi; below the thresholds the generic kernel wins: tools/mm_thresholds.py);
  *   0 = never (the generic kernel: a wave runs at the level of its most refined lane); 2 = always.
  *   "park_cap": records per workgroup (0 = what fits in LDS beside the tables; a flagged lane that finds none free is
  *   taken again from its loads at the end of the launch, in place).  "record_group_min" (1..64, default 64): that many

@@ -508,14 +508,14 @@ template <int LEVEL, typename T, typename P, typename PR, bool HAVE_F1 = false, 
 __device__ __forceinline__ void split_level(P& p, const PR& pr, const MinuteIn<T>& u, T (&x)[13], int n_sub, T f1_pre = T(0),
                                             bool refine = false, const T* hc = nullptr)
 {
-    static_assert(!HC || LEVEL != 0, "step sizes from memory: compile-time levels only");
+    // (HC at LEVEL 0: hc holds level 1's five words followed by level 2's)
     const bool r2 = LEVEL == 2 || (LEVEL == 0 && refine);        // this lane at level 2
     const int sb = r2 ? 1 : 2;                                    // propagator blocks per glucose half step
     const int nh = r2 ? 2 * n_sub : n_sub;                        // glucose half steps = gut steps in the minute
     const int ns = nh >> 1;
     T h, H, H6, hh, h6;                                           // h: glucose half step = gut step
     if (HC) {
-        int z = 0;
+        int z = LEVEL == 0 && r2 ? 5 : 0;
         asm volatile("" : "+v"(z));
         h = hc[z]; hh = hc[z + 1]; h6 = hc[z + 2]; H = hc[z + 3]; H6 = hc[z + 4];
     } else {

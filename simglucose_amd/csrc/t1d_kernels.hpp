@@ -1106,6 +1106,14 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
 #pragma unroll
         for (int k = 0; k < 4; ++k) p.v[kSplitW(1) + k] = pl(kSplitW(1) + k);
     };
+    // ... and for the records: the weights of both levels (a lone wave cannot hide the LDS latency of ~200 parameter reads
+    // per minute behind anything: from LDS the pass over the records took three times as long)
+    auto gather_pars2 = [&](ParsReg<T>& p, uint32_t pid) {
+        gather_pars(p, pid);
+        ParsLdsS<T, STRIDE> pl{ldp, (int)pid};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p.v[kSplitW(2) + k] = pl(kSplitW(2) + k);
+    };
     // one minute of a chunk at level 1: step sizes from LDS
     auto integrate = [&](ParsReg<T>& p, SnLane<T>& L, const MinuteIn<T>& u, T f1) {
         PropLdsS<T, STRIDE> pr{lpr, (int)L.pid};
@@ -1267,6 +1275,10 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
                 active = ((redo[w_redo] >> lane) & 1ull) != 0ull;
                 load_lane(L, (int64_t)i < a.n ? i : (unsigned)(a.n - 1));
             }
+            // (fp64; the fp32 instantiation has no registers to spare at four waves per SIMD and keeps reading LDS)
+            constexpr bool kRecReg = sizeof(T) == 8;
+            ParsReg<T> p;
+            if constexpr (kRecReg) gather_pars2(p, L.pid);
             for (;;) {
                 const bool on = active && L.m < a.minutes;
                 if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;             // wave-uniform
@@ -1279,9 +1291,14 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
                     const MinuteIn<T> u = minute_head(L, meal, tp);
                     L.dirty |= ((L.planned != planned0 || L.lq != lq0 || L.lf != lf0) ? 1 : 0) | (L.next_meal != nm0 ? 2 : 0) |
                                ((L.cursor != cur0 || L.eating != eat0) ? 4 : 0);
-                    ParsLdsS<T, STRIDE> pl{ldp, (int)L.pid};
                     PropLdsS<T, STRIDE> pr{lpr, (int)L.pid};
-                    split_level<0, T, ParsLdsS<T, STRIDE>, decltype(pr), true>(pl, pr, u, L.x, a.n_sub, tp.f1, tp.level2);
+                    if constexpr (kRecReg) {
+                        p.pin_split();
+                        split_level<0, T, ParsReg<T>, decltype(pr), true, true>(p, pr, u, L.x, a.n_sub, tp.f1, tp.level2, lconst + 8);
+                    } else {
+                        ParsLdsS<T, STRIDE> pl{ldp, (int)L.pid};
+                        split_level<0, T, ParsLdsS<T, STRIDE>, decltype(pr), true>(pl, pr, u, L.x, a.n_sub, tp.f1, tp.level2);
+                    }
                     minute_tail(L, meal);
                     L.m += 1;
                 }
