@@ -420,6 +420,25 @@ def main(argv=None):
         wall = float(tw.item())
     kern_ms = ev0.elapsed_time(ev1) / a.steps
     total_env_steps = n_global * a.steps * st
+    # the optional exchange of the N > 1 job (north_star: "an optional RCCL gather of observations over xGMI"), outside the
+    # timed region: every rank's CGM slice gathered into one [N] tensor on every rank, as a central policy would ask for
+    gather = None
+    if use_dist:
+        from simglucose_amd.distributed import gather_observations
+        try:
+            full = gather_observations(env.cgm, n_global, force_collective=True)
+            ok = bool(torch.equal(full[env_offset:env_offset + n], env.cgm)) and full.numel() == n_global
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(20):
+                full = gather_observations(env.cgm, n_global, force_collective=True)
+            torch.cuda.synchronize()
+            tgw = torch.tensor([(time.perf_counter() - tg) / 20], dtype=torch.float64, device=dev)
+            dist.all_reduce(tgw, op=dist.ReduceOp.MAX)
+            gather = {"ms": float(tgw.item()) * 1e3, "bytes_gathered_per_rank": n_global * env.cgm.element_size(), "slices_in_place": ok,
+                      "collective": "all_gather_into_tensor (RCCL)", "note": "not part of `value`: the step path needs no collective"}
+        except Exception as e:
+            gather = {"error": repr(e)}
     # N > 1 under strong scaling: each rank's shard is small and its launch latency-bound; the same job
     # with a full-size batch on every rank (what --scaling weak times) is measured beside it, outside the timed region
     weak = None
@@ -477,7 +496,7 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": ALGO_BYTES[a.dtype], "valu": valu},
-            "accuracy": accuracy, "north_star_rk4": rk4, "weak_scaling_probe": weak,
+            "accuracy": accuracy, "north_star_rk4": rk4, "weak_scaling_probe": weak, "observation_gather": gather,
             "sane": sane, "status_bits": status,
             "bg_mean": float(bg.mean()), "bg_min": float(bg.min()), "bg_max": float(bg.max()),
         }

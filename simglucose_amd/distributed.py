@@ -17,9 +17,10 @@ def shard_range(n_total, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_observations(local, n_total=None, group=None):
-    """local [n_r] on every rank -> [N] on every rank (rank order).  Shards may differ in size by one."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def gather_observations(local, n_total=None, group=None, force_collective=False):
+    """local [n_r] on every rank -> [N] on every rank (rank order).  Shards may differ in size by one.
+    force_collective: run the collective with a single rank too (rehearsals of the N > 1 path on one GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if n_total is None:
