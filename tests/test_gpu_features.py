@@ -838,6 +838,60 @@ def test_full_size_24h_run_sampled_envs_match_oracle(adaptive):
     assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K == int(e.t.max())
 
 
+@pytest.mark.parametrize("sensor,hours", [("Dexcom", 12), ("GuardianRT", 6)])
+def test_full_size_multi_minute_steps_sampled_envs_match_oracle(sensor, hours):
+    """The reference's own step shape (env.py:75-81: sample_time mini-steps per env.step, Dexcom 3 / GuardianRT 5) at
+    BASELINE's full size with the library's defaults -- 1 048 576 fp64 envs: the persistent multi-minute kernel, one launch
+    per step --, random-action policy, random meal tables, Philox noise.  300 envs sampled across the batch (every patient,
+    first and last workgroups, wave edges) replayed on the oracle with the very normals, meals and actions the kernel used:
+    observation (mean of held and fresh CGM samples), mean BG, reward, done and meal agree to 1e-8 throughout, the final
+    states to 1e-6; against the oracle's SciPy-faithful DOPRI5 path the BG stays within the bounds of the 1-minute test."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    from oracle import t1d_oracle as O
+    n = 1 << 20
+    pid = np.arange(n) % 30
+    e = _mk(patient=pid, sensor=sensor, noise="philox", seed=78, n_sub=4, extra_outputs=True)
+    st = int(e.sample_time)
+    K = hours * 60 // st
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=5 * 60, seed=6, device=e.device)
+    e.set_meals(mt, ma)
+    rs = np.random.RandomState(2)
+    sample = np.unique(np.concatenate([np.arange(0, 130), np.arange(n - 130, n), rs.randint(0, n, 60)]))[:300]
+    sidx = torch.as_tensor(sample, device=e.device)
+    z = e.philox_normals(1 + 10 * (2 + K * st // 150), draw0=0, episode=1)[:, sidx].cpu().numpy()
+    t_s, a_s = mt[:, sample].cpu().numpy().astype(np.int64), ma[:, sample].cpu().numpy()
+    cho = np.zeros((K * st, len(sample)))
+    for j in range(len(sample)):
+        for tt, aa in zip(t_s[:, j], a_s[:, j]):
+            if tt < K * st:
+                cho[tt, j] = aa
+    b0 = torch.as_tensor(_basal(pid), device=e.device)
+    g = torch.Generator(device=e.device); g.manual_seed(4)
+    pool = [(b0 * 2.0 * torch.rand(n, generator=g, device=e.device, dtype=torch.float64)).contiguous() for _ in range(8)]
+    pool_s = [p[sidx].cpu().numpy() for p in pool]
+    orc = O.OracleEnv(pid[sample], sensor=sensor, normals=z, integrator="split_adaptive", n_sub=4)
+    ref = O.OracleEnv(pid[sample], sensor=sensor, normals=z, integrator="dopri")
+    o0, r0 = e.reset(), orc.reset()
+    ref.reset()
+    assert np.abs(o0[sidx].cpu().numpy() - r0["cgm"]).max() < 1e-9
+    worst = 0.0
+    worst_env = np.zeros(len(sample))
+    for k in range(K):
+        e.step(pool[k % 8])
+        r = orc.step(pool_s[k % 8], None, cho[k * st:(k + 1) * st])
+        rr = ref.step(pool_s[k % 8], None, cho[k * st:(k + 1) * st])
+        if k % 8 == 7 or k == K - 1:
+            for key in ("cgm", "bg", "reward", "meal"):
+                worst = max(worst, np.abs(getattr(e, key)[sidx].cpu().numpy() - r[key]).max())
+            assert np.array_equal(e.done[sidx].cpu().numpy().astype(bool), np.asarray(r["done"], bool)), k
+            worst_env = np.maximum(worst_env, np.abs(e.bg[sidx].cpu().numpy() - rr["bg"]))
+    assert worst < 1e-8, worst
+    assert (worst_env <= 1e-3).mean() >= 0.985 and np.median(worst_env) < 1.0e-4, ((worst_env <= 1e-3).mean(), np.median(worst_env), worst_env.max())
+    assert np.abs(e.x[:, sidx].cpu().numpy() - orc.x).max() < 1e-6
+    assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K * st == int(e.t.max())
+
+
 @pytest.mark.parametrize("sensor,dtype_name,form", [("Dexcom", "f64", "default"), ("GuardianRT", "f64", "default"), ("Dexcom", "f32", "default"),
                                                     ("Dexcom", "f64", "small_park"), ("Dexcom", "f64", "in_place"), ("Dexcom", "f64", "fixed"),
                                                     ("GuardianRT", "f32", "small_park")])
