@@ -125,6 +125,47 @@ def test_config5_pid_rollout_7_days_sampled_envs_vs_oracle(dtype_name):
     assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K * st == int(e.t.max())
 
 
+def test_pid_rollout_1mi_envs_launch_per_step_sampled_envs_vs_oracle():
+    """The in-kernel PID closed loop at 1 048 576 fp64 envs, where the library's defaults run it as one launch of the persistent
+    multi-minute kernel per step with the controller fused in (t1d.h "rollout_launches"): 8 h of Dexcom steps in calls of 1,
+    39 and 120 steps, milder gains than config 5's; 200 envs sampled across the batch (first and last workgroups, every
+    patient) follow the oracle's closed loop -- same scheme, the kernel's own normals and meals -- to 1e-8 mg/dL, and the
+    controller state to rounding."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    from oracle import t1d_oracle as O
+    n, st, K = 1 << 20, 3, 160
+    pid = np.arange(n) % 30
+    e = _mk(patient=pid, sensor="Dexcom", noise="philox", seed=56, n_sub=4)
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=6 * 60, seed=22, device=e.device)
+    e.set_meals(mt, ma)
+    rs = np.random.RandomState(3)
+    sample = np.unique(np.concatenate([np.arange(0, 70), np.arange(n - 70, n), rs.randint(0, n, 60)]))[:200]
+    sidx = torch.as_tensor(sample, device=e.device)
+    z = e.philox_normals(1 + 10 * (2 + K * st // 150), draw0=0, episode=1)[:, sidx].cpu().numpy()
+    cho = _dense_cho(mt, ma, sample, K * st)
+    orc = O.OracleEnv(pid[sample], sensor="Dexcom", normals=z, integrator="split_adaptive", n_sub=4)
+    e.reset()
+    r = orc.reset()
+    P, I, D, target = 1.5e-4, 4e-7, 5e-4, 140.0
+    obs = r["cgm"].copy(); integ = np.zeros(len(sample)); prev = np.zeros(len(sample))
+    tr = e.new_trace(K, columns=("bg", "cgm"))
+    state = None
+    for chunk in (1, 39, 120):
+        state = e.rollout_pid(chunk, P, I, D, target, pid_state=state, trace=tr)
+    ref_bg, ref_cgm = np.empty((K, len(sample))), np.empty((K, len(sample)))
+    for k in range(K):
+        u = P * (obs - target) + I * integ + D * (obs - prev) / st            # pid_ctrller.py:17-36
+        prev = obs.copy(); integ = integ + (obs - target) * st
+        o = orc.step(u, None, cho[k * st:(k + 1) * st])
+        obs = o["cgm"]; ref_bg[k] = o["bg"]; ref_cgm[k] = o["cgm"]
+    assert np.abs(tr["bg"][1:, sidx].cpu().numpy() - ref_bg).max() < 1e-8
+    assert np.abs(tr["cgm"][1:, sidx].cpu().numpy() - ref_cgm).max() < 1e-8
+    assert np.abs(state["integ"][sidx].cpu().numpy() - integ).max() < 1e-6 * max(1.0, np.abs(integ).max())
+    assert np.abs(state["prev"][sidx].cpu().numpy() - prev).max() < 1e-8
+    assert e.sync() == 0 and bool(torch.isfinite(e.bg).all()) and int(e.t.min()) == K * st == int(e.t.max())
+
+
 def test_config5_262144_envs_7_days_properties():
     """Config 5 at its stated size (262 144 envs, fp32, 7 days of in-kernel PID closed loop in launches of 480 steps):
     size-independent properties -- every env reaches minute 10 080 with a finite state and no status bit; identical
