@@ -941,6 +941,48 @@ def test_multi_minute_kernel_equals_generic_kernel(sensor, dtype_name, form):
     assert envs[0].sync() == 0 and envs[1].sync() == 0
 
 
+def test_multi_minute_kernel_odd_shapes_equal_generic_kernel():
+    """The persistent multi-minute kernel against the generic kernel over shapes and settings picked to hit its edges: 1,
+    63, 65, 640, 4 099 and 70 001 envs (partial chunks, fewer chunks than waves), both sensors and dtypes, n_sub 2-8,
+    record capacities 0 (everything through the redo map) to 300, records going ahead of chunks from 1 waiting, grids of 1,
+    3 and 17 workgroups, and a masked reset of a third of the envs in the middle.  80 steps each; outputs, clocks, meta words
+    and states agree (fp64: rounding; fp32: 5e-3) and no status bit is raised."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    rs = np.random.RandomState(0)
+    cases = []
+    for n in (1, 63, 65, 640, 4099, 70001):
+        for sensor in ("Dexcom", "GuardianRT"):
+            for dt in (torch.float64, torch.float32):
+                cases.append((n, sensor, dt, int(rs.choice([2, 4, 6, 8])), int(rs.choice([0, 1, 7, 64, 300])), int(rs.choice([1, 5, 64])),
+                              int(rs.choice([0, 1, 3, 17])), bool(rs.rand() < 0.5)))
+    for (n, sensor, dt, n_sub, park, gmin, blocks, extra) in cases:
+        pid = rs.randint(0, 30, n)
+        mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=7 * 60, seed=int(rs.randint(1 << 20)), device="cuda:0", dtype=dt)
+        envs = []
+        for mode in (0, 2):
+            e = _mk(patient=pid, sensor=sensor, dtype=dt, noise="philox", seed=9, n_sub=n_sub, extra_outputs=extra)
+            for k, v in (("multi_minute_kernel", mode), ("park_cap", park), ("record_group_min", gmin), ("s1_blocks", blocks)):
+                e.set_option(k, v)
+            e.set_meals(mt, ma); e.reset(); envs.append(e)
+        b = torch.as_tensor(_basal(pid), device="cuda:0", dtype=dt)
+        tol = 1e-9 if dt == torch.float64 else 5e-3
+        case = (n, sensor, str(dt), n_sub, park, gmin, blocks, extra)
+        for k in range(80):
+            if k == 40:
+                m = torch.as_tensor(np.arange(n) % 3 == 0, device="cuda:0")
+                for e in envs:
+                    e.reset(mask=m)
+            for e in envs:
+                e.step(b * (0.3 + 0.4 * (k % 5)))
+            if k % 10 == 9 or k == 40:
+                for key in ("cgm", "bg", "reward"):
+                    assert float((getattr(envs[0], key) - getattr(envs[1], key)).abs().max()) < tol, (case, k, key)
+        assert torch.equal(envs[0].t, envs[1].t) and torch.equal(envs[0].meta, envs[1].meta), case
+        assert float((envs[0].x - envs[1].x).abs().max()) < tol * 100, case
+        assert envs[0].sync() == 0 and envs[1].sync() == 0, case
+
+
 @pytest.mark.parametrize("dtype_name,ctrl", [("f64", "pid"), ("f64", "bb"), ("f32", "pid")])
 def test_rollout_as_one_launch_per_step_equals_single_launch_rollout(dtype_name, ctrl):
     """t1d_rollout_pid / t1d_rollout_bb as one launch of the multi-minute kernel per step (controller fused into the launch,
