@@ -253,6 +253,11 @@ int t1d_ctx_destroy(t1d_ctx* ctx);
  *   taken again from its loads at the end of the launch, in place).  "record_group_min" (1..64, default 64): that many
  *   waiting records go ahead of a wave's next chunk (fewer: the records start earlier but in emptier waves -- measured
  *   slower from 512 Ki envs up, 3-5 % faster at 256 Ki).
+ * "pingpong": 1 (default) = the persistent kernels walk every compute unit's chunks from the last to the first in every
+ *   other launch, so that a launch starts on the lines the launch before it touched last -- what the 256 MB Infinity Cache
+ *   in front of HBM still holds (walked in the same order every launch, a working set of about the cache's size is the
+ *   pattern an LRU cache serves worst).  One-minute launches: no difference at 1 Mi fp64 envs, 5 % faster at 2 Mi, 8 % at
+ *   4 Mi (80 us per Mi envs).  Results do not depend on it.  0 = always first to last.
  * "rollout_launches": t1d_rollout_pid / t1d_rollout_bb as one launch of that kernel per step, the controller fused into
  *   it: 1 (default) = batches of "rollout_launches_min_envs" (fp64: 524 288) / "rollout_launches_min_envs_f32" (786 432)
  *   envs or more; 0 = never (all steps inside one launch of the generic roll-out kernel); 2 = always. */

@@ -43,6 +43,8 @@ struct t1d_ctx {
     int multi_minute_kernel = 1;     // steps of several minutes (minutes <= sample_time) on the packed layout through the persistent kernel with the state in registers across the minutes: 0 never (generic kernel), 1 = fp64 batches of multi_minute_min_envs envs or more, 2 always
     int multi_minute_min_envs = 262144, multi_minute_min_envs_f32 = 393216;      // measured crossovers: tools/mm_thresholds.py
     int park_cap = 0;                // records for set-aside lanes per workgroup of that kernel (0 = what fits in LDS; tests force the overflow path with a small one)
+    int pingpong = 1;                // the persistent one-minute kernels walk a CU's chunks backwards in every other launch (below)
+    mutable unsigned launches = 0;   // one-minute launches so far
     int record_group_min = 64;       // the multi-minute kernel: that many waiting records go ahead of a wave's next chunk
     int rollout_launches = 1;        // closed-loop roll-outs as one launch of that kernel per step: 0 never (all steps inside one launch of the generic kernel), 1 from rollout_launches_min_envs envs up, 2 always
     int rollout_launches_min_envs = 524288, rollout_launches_min_envs_f32 = 786432;
@@ -345,6 +347,7 @@ extern "C" int t1d_ctx_set_option(t1d_ctx* c, const char* name, int64_t value)
         {"multi_minute_min_envs", &t1d_ctx::multi_minute_min_envs, 0, 1 << 28},
         {"multi_minute_min_envs_f32", &t1d_ctx::multi_minute_min_envs_f32, 0, 1 << 28},
         {"park_cap", &t1d_ctx::park_cap, 0, 65535},
+        {"pingpong", &t1d_ctx::pingpong, 0, 1},
         {"record_group_min", &t1d_ctx::record_group_min, 1, 64},
         {"rollout_launches", &t1d_ctx::rollout_launches, 0, 2},
         {"rollout_launches_min_envs", &t1d_ctx::rollout_launches_min_envs, 0, 1 << 28},
@@ -424,7 +427,7 @@ static KArgs<T> make_args(const t1d_ctx* c, const t1d_batch* b, int minutes, int
     a.pump.min_bolus = (T)c->pump[0]; a.pump.max_bolus = (T)c->pump[1]; a.pump.inc_bolus = (T)c->pump[2];
     a.pump.min_basal = (T)c->pump[3]; a.pump.max_basal = (T)c->pump[4]; a.pump.inc_basal = (T)c->pump[5];
     a.np = c->np; a.S = c->S; a.n_meals = b->n_meals; a.n_normals = b->n_normals;
-    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags;
+    a.minutes = minutes; a.n_sub = n_sub; a.flags = b->flags | (c->pingpong && (c->launches & 1) ? kFlagReverse : 0);
     a.prop = sizeof(T) == 8 ? (const T*)c->d_prop64 : (const T*)c->d_prop32;
     a.prop_rows = c->split_nsub ? kPropRows(c->split_nsub) : 0; a.np_pad = c->np_pad;
     return a;
@@ -539,6 +542,7 @@ static int launch_stepn(t1d_ctx* c, const t1d_batch* b, const PersistPlan& p, in
 {
     T1D_HIP(allow_lds(c, (const void*)stepn_kernel<T, EXTRA, CTRL>, dyn));
     const int mode = (c->adaptive_gut != 0 ? 1 : 0) | (c->adaptive_gut == 2 ? 2 : 0) | (c->record_group_min << 8);
+    ++c->launches;
     hipLaunchKernelGGL((stepn_kernel<T, EXTRA, CTRL>), dim3(p.blocks), dim3(sn_threads<T>()), dyn, s, make_args<T>(c, b, minutes, n_sub), pa,
                        p.nchunks, cap, mode);
     return T1D_OK;
@@ -624,6 +628,7 @@ extern "C" int t1d_step(t1d_ctx* c, const t1d_batch* b, int minutes, int n_sub, 
 #define T1D_S1_BY(TT, ST) do { if (tiered) { if (extra) T1D_LAUNCH_S1(TT, ST, true, true); else T1D_LAUNCH_S1(TT, ST, false, true); } \
                                else { if (extra) T1D_LAUNCH_S1(TT, ST, true, false); else T1D_LAUNCH_S1(TT, ST, false, false); } } while (0)
 #define T1D_S1D_BY(TT) do { if (extra) T1D_LAUNCH_S1D(TT, true); else T1D_LAUNCH_S1D(TT, false); } while (0)
+        ++c->launches;
         if (defer) {
             if (b->dtype == T1D_F64) T1D_S1D_BY(double); else T1D_S1D_BY(float);
         } else if (b->dtype == T1D_F64) {

@@ -31,6 +31,11 @@
 // Tuning builds only (-DT1D_AB_FLAGS=1): bits 0x100 / 0x200 / 0x400 / 0x800 of t1d_batch.flags switch the risk index,
 // the pump, the CGM noise and the integration off, to time the rest.  The shipped library is built without them and
 // t1d_step rejects unknown flag bits.
+// internal bit of KArgs.flags (never in t1d_batch.flags): this launch walks every CU's chunks from the last to the first.
+// A launch of 1 Mi fp64 envs touches ~215 MB, about what the 256 MB Infinity Cache in front of HBM holds: walked in the same
+// order every launch that is the access pattern an LRU cache serves worst (each line is evicted just before it is wanted
+// again); back and forth, a launch starts on what the one before it touched last.
+constexpr int kFlagReverse = 0x10000;
 #ifndef T1D_AB_FLAGS
 #define T1D_AB_FLAGS 0
 #endif
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(s1d_threads<T>(), 1) void step1d_kernel(const KArgs
     for (;; ++it) {
         const int c = draw(&queue);
         if (c >= count) break;                              // wave-uniform
-        const unsigned i = (unsigned)(first + c) * 64u + lane;
+        const unsigned i = (unsigned)(first + ((a.flags & kFlagReverse) ? count - 1 - c : c)) * 64u + lane;
         __builtin_assume(i < (1u << 28));
         if ((int64_t)i < a.n) {
 #if T1D_S1_TRACE
@@ -1307,7 +1312,7 @@ __global__ __launch_bounds__(sn_threads<T>(), 1) void stepn_kernel(const KArgs<T
             continue;
         }
         // ---- a chunk
-        const unsigned i0 = (unsigned)(first + w_chunk) * 64u + lane;
+        const unsigned i0 = (unsigned)(first + ((a.flags & kFlagReverse) ? count - 1 - w_chunk : w_chunk)) * 64u + lane;   // (kFlagReverse: above)
         __builtin_assume(i0 < (1u << 28));
         bool left = (int64_t)i0 >= a.n;                     // lanes beyond the batch have nothing to finish
         SnLane<T> L;

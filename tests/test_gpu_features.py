@@ -941,6 +941,30 @@ def test_multi_minute_kernel_equals_generic_kernel(sensor, dtype_name, form):
     assert envs[0].sync() == 0 and envs[1].sync() == 0
 
 
+@pytest.mark.parametrize("sensor", ["Navigator", "Dexcom"])
+def test_chunk_order_of_a_launch_does_not_change_results(sensor):
+    """The persistent kernels walk a CU's chunks backwards in every other launch (t1d.h "pingpong": the next launch starts on
+    what this one touched last, which is what the Infinity Cache still holds).  Envs are independent, so the order must not
+    show: with and without it the outputs and states are bit-identical over 40 steps."""
+    import torch
+    from simglucose_amd import scenario_batch as sb
+    n = 64 * 300 - 7
+    pid = np.arange(n) % 30
+    mt, ma = sb.random_meal_tables(n, days=1, start_minute_of_day=7 * 60, seed=4, device="cuda:0")
+    envs = []
+    for pp in (0, 1):
+        e = _mk(patient=pid, sensor=sensor, noise="philox", seed=10, n_sub=4, extra_outputs=True)
+        e.set_option("pingpong", pp); e.set_option("multi_minute_kernel", 2)
+        e.set_meals(mt, ma); e.reset(); envs.append(e)
+    b = torch.as_tensor(_basal(pid), device="cuda:0")
+    for k in range(40):
+        for e in envs:
+            e.step(b * (0.5 + 0.25 * (k % 4)))
+    for key in ("x", "cgm", "bg", "reward", "risk", "prev_risk", "planned", "last_qsto", "last_food", "dbar", "t", "meta", "next_meal", "done"):
+        assert torch.equal(getattr(envs[0], key), getattr(envs[1], key)), key
+    assert envs[0].sync() == 0 and envs[1].sync() == 0
+
+
 def test_multi_minute_kernel_odd_shapes_equal_generic_kernel():
     """The persistent multi-minute kernel against the generic kernel over shapes and settings picked to hit its edges: 1,
     63, 65, 640, 4 099 and 70 001 envs (partial chunks, fewer chunks than waves), both sensors and dtypes, n_sub 2-8,
