@@ -1,3 +1,7 @@
+#!/bin/bash
+# SQ counters of the headline launch under the timing-only batch flags of a tuning build (GPU box).  Needs a -DT1D_AB_FLAGS=1
+# build of the library at exp/libt1d_ab.so (hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC
+# -DT1D_AB_FLAGS=1 -Iinclude -o exp/libt1d_ab.so simglucose_amd/csrc/t1d_abi.hip; exp/ is git-ignored scratch that travels to the box).
 export T1D_LIB_PATH=$PWD/exp/libt1d_ab.so
 root=$PWD; out=$root/gpurun_out; cd /tmp; export TMPDIR=/tmp
 for cfg in "0 --opt levels=2" "0" "2000"; do
